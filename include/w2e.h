@@ -1,0 +1,114 @@
+/* w2e.h -- C ABI of libw2e.so: the MI355X (gfx950) kernels for the Where2edit
+ * latent-editing hot path.
+ *
+ * The reference (Big-Brother-Pikachu/Where2edit) has no native code and no FFI:
+ * its "operator seam" is the Python export list of models/stylegan2/op/__init__.py:1-2
+ * plus the torch op sequences inside models/stylegan2/model.py, attention/attention_model.py
+ * and criteria/clip_loss.py.  Each entry point below names the reference lines whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch types; every pointer is a DEVICE pointer to contiguous fp32
+ *     (NCHW for images) unless stated; the CALLER allocates outputs and workspaces;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it,
+ *     never synchronises, never allocates (safe under hipGraph capture);
+ *   - returns 0 on success, non-zero on error; w2e_last_error() then describes it
+ *     (thread-local); nothing throws across the ABI; no global mutable state.
+ */
+#ifndef W2E_H
+#define W2E_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2E_VERSION 1
+
+int w2e_version(void);
+const char* w2e_last_error(void);
+
+/* ---- K2  upfirdn2d  (models/stylegan2/op/upfirdn2d.py:11-60) ---------------------------
+ * y[p,oy,ox] = sum_{ky,kx} kern'[ky,kx] * xz[p, oy*down + ky - pad_y0, ox*down + kx - pad_x0]
+ * where xz is x zero-stuffed by `up` (sample at multiples of up) and zero outside, and
+ * kern' = kern flipped in both axes when flip != 0 (flip=1 is the reference forward: a true
+ * convolution; flip=0 with swapped up/down is its adjoint, used for backward).
+ * planes = N*C.  kern is [kh,kw] on the device, kh,kw <= 16.
+ * Optional fused epilogue (StyledConv after the blur, model.py:260,290 + op/fused_act.py:23-39):
+ *   y = lrelu(out_scale[p]*y + noise_w[0]*noise[oy,ox] + bias[p % channels], slope) * gain
+ * enabled when act != 0; out_scale / noise / bias may be NULL (treated as 1 / 0 / 0). */
+int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, int in_h, int in_w, int out_h,
+                  int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip,
+                  int act, const float* out_scale, const float* noise, const float* noise_w, const float* bias,
+                  int channels, float slope, float gain, void* stream);
+
+/* ---- K3  bias (+noise) + leaky-relu * gain  (op/fused_act.py:23-39, model.py:285-290) -----
+ * x viewed as [outer, channels, inner]; bias[channels] or NULL; noise[inner] or NULL with device
+ * scalar noise_w.  y = lrelu(x + noise_w*noise[i] + bias[c], slope) * gain. */
+int w2e_bias_act_fwd(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
+                     int64_t outer, int64_t channels, int64_t inner, float slope, float gain, void* stream);
+/* gx = gy * gain * (y > 0 ? 1 : slope)   (sign of the pre-activation == sign of y). */
+int w2e_bias_act_bwd(const float* gy, const float* y, float* gx, int64_t n, float slope, float gain, void* stream);
+/* Same, plus the per-(outer,channel) reductions the demodulation / bias / noise-strength
+ * gradients need (one pass over gy,y):  sums[(o*channels+c)*3 + {0,1,2}] =
+ *   sum_i gx*pre, sum_i gx*noise[i], sum_i gx   with pre = y>0 ? y/gain : y/(gain*slope).
+ * sums must hold outer*channels*3 floats (written, not accumulated). */
+int w2e_bias_act_bwd_reduce(const float* gy, const float* y, const float* noise, float* gx, float* sums,
+                            int64_t outer, int64_t channels, int64_t inner, float slope, float gain, void* stream);
+
+/* ---- K1  modulated 3x3 convolution on fp32 MFMA  (model.py:234-276) -----------------------
+ * Shared-weight form of ModulatedConv2d:  the reference materialises w'[b,o,i,k] =
+ * scale*W[o,i,k]*s[b,i]*demod[b,o] per sample; here
+ *     y[b,o] = out_scale[b,o] * conv(Wp, in_scale[b,i] * x[b,i])
+ * with one packed weight tensor shared by the batch.  Forward: in_scale = s, out_scale = demod.
+ * Input-gradient: the same kernel on the flipped/transposed pack with in_scale = demod, out_scale = s.
+ *
+ * w2e_conv_pack: weight [cout,cin,3,3] -> wp [K][9][N] (N contiguous), multiplied by `scale`:
+ *   transpose=0: K=cin, N=cout (forward);  transpose=1: K=cout, N=cin (input gradient);
+ *   flip=1 reverses the 9 taps (stride-1 input gradient); flip=0 keeps them. */
+int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, float scale, int transpose, int flip,
+                  void* stream);
+
+#define W2E_CONV_SAME 0 /* stride 1, zero pad 1: [B,K,H,W] -> [B,N,H,W]              (model.py:270-274) */
+#define W2E_CONV_UP 1   /* conv_transpose stride 2, pad 0: -> [B,N,2H+1,2W+1]        (model.py:249-259) */
+#define W2E_CONV_DOWN 2 /* stride 2, pad 0 on [B,K,2H+1,2W+1] -> [B,N,H,W] (adjoint of UP) */
+
+/* Epilogue (applied after out_scale), all optional:
+ *   act != 0:   y = lrelu(y + noise_w[0]*noise[h,w] + bias[o], 0.2) * sqrt(2)   (SAME only)
+ *   dot_with/dot_out: dot_out[b,o] += sum_p conv_unscaled[b,o,p] * dot_with[b,o,p]
+ *                     (the direct style gradient sum_p x*g; dot_out must be zeroed by the caller).
+ * h,w are the INPUT spatial size for SAME/UP and the OUTPUT size for DOWN. */
+int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                   float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
+                   const float* noise_w, const float* bias, const float* dot_with, float* dot_out, void* stream);
+
+/* ---- K1r  ToRGB: modulated 1x1 conv (no demod) + bias + upsampled skip  (model.py:343-362) --
+ * wmod [B,3,cin] = scale*W[c,i]*s[b,i] (tiny, built by the host);  skip [B,3,h/2,w/2] or NULL is
+ * up-sampled x2 with the 4x4 kernel `upk` (Upsample, model.py:31-49: up=2, pad (2,1)) and added. */
+int w2e_torgb_fwd(const float* x, const float* wmod, const float* bias, const float* skip, const float* upk,
+                  float* y, int batch, int cin, int h, int w, void* stream);
+/* gx[b,i,p] = sum_c wmod[b,c,i]*gy[b,c,p];  gwmod[b,c,i] = sum_p x[b,i,p]*gy[b,c,p] (written). */
+int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx, float* gwmod, int batch, int cin,
+                  int h, int w, void* stream);
+
+/* ---- K5  CLIP preprocessing  (criteria/clip_loss.py:11-12,15) ------------------------------
+ * AvgPool2d(size/32)(Upsample(x7, nearest)(img)) in closed form: [planes,size,size] -> [planes,224,224];
+ * never materialises the 7x image.  bwd is the exact adjoint. */
+int w2e_clip_preproc_fwd(const float* img, float* out, int64_t planes, int size, void* stream);
+int w2e_clip_preproc_bwd(const float* gout, float* gimg, int64_t planes, int size, void* stream);
+
+/* ---- K6  region-attention blend  (attention/attention_model.py:548-549 and siblings) --------
+ * m = nearest-resize(mask[B,1,ms,ms]) to [h,w];  out = m*a + (1-m)*b, a,b [B,C,h,w]. */
+int w2e_mask_blend_fwd(const float* a, const float* b, const float* mask, float* out, int batch, int channels,
+                       int h, int w, int ms, void* stream);
+/* ga = m*gout; gb = (1-m)*gout (gb may be NULL); gmask[b,my,mx] = sum over channels and covered
+ * pixels of gout*(a-b) (gmask may be NULL; written, not accumulated). */
+int w2e_mask_blend_bwd(const float* gout, const float* a, const float* b, const float* mask, float* ga, float* gb,
+                       float* gmask, int batch, int channels, int h, int w, int ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2E_H */

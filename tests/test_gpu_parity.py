@@ -1,0 +1,342 @@
+"""Parity of the HIP path (through the C ABI) against (a) golden vectors captured from the reference
+and (b) the CPU oracle on seeded inputs.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances: BASELINE.json:north_star states 1e-3 relative fp32 on outputs; the tests hold forward
+results to 1e-4 (max-abs error / max-abs reference) and single-op gradients to 1e-3."""
+import math
+
+import pytest
+import torch
+
+import seeded
+from helpers import assert_close, assert_grad_close, golden, rel_err
+from make_golden import MODCONV_CASES, UPFIRDN_CASES, _kernel, modconv_inputs
+from oracle import ops as O
+from oracle import stylegan2 as OG
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FWD_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------ upfirdn2d
+@pytest.mark.parametrize("case", UPFIRDN_CASES, ids=[c[0] for c in UPFIRDN_CASES])
+def test_upfirdn2d_golden(case):
+    from where2edit_amd.op import upfirdn2d
+    g = golden("ops")
+    name, shape, kspec, gain, up, down, pad = case
+    x = cu(seeded.tensor("upfirdn." + name, shape)).requires_grad_(True)
+    y = upfirdn2d(x, cu(_kernel(kspec, gain)), up=up, down=down, pad=pad)
+    assert_close(y, g[f"upfirdn.{name}.y"], 1e-5, "y")
+    (gx,) = torch.autograd.grad(y, x, cu(seeded.tensor("upfirdn.gy." + name, y.shape)))
+    assert_close(gx, g[f"upfirdn.{name}.gx"], 1e-5, "gx")
+
+
+@pytest.mark.parametrize("shape,up,down,pad,ktaps", [
+    ((2, 8, 65, 65), 1, 1, (1, 1), (1, 3, 3, 1)),      # tile kernel, ragged edge
+    ((1, 3, 129, 257), 1, 1, (1, 1), (1, 3, 3, 1)),    # 2H+1 sizes, non-square
+    ((2, 3, 32, 32), 2, 1, (2, 1), (1, 3, 3, 1)),      # RGB skip up-sampling
+    ((1, 4, 64, 64), 1, 2, (1, 1), (1, 3, 3, 1)),      # down-sampling
+    ((1, 2, 40, 24), 1, 1, (3, 3), (1, 4, 6, 4, 1)),   # 5-tap kernel through the tile kernel
+    ((1, 1, 16, 16), 1, 1, (0, 0), (1,)),              # 1x1 kernel = identity
+])
+def test_upfirdn2d_vs_oracle_and_adjoint(shape, up, down, pad, ktaps):
+    from where2edit_amd.op import upfirdn2d
+    k = O.make_kernel(ktaps) * (up ** 2)
+    x = seeded.tensor("ufd.x", shape)
+    y_ref = O.upfirdn2d(x, k, up, down, pad)
+    xg = cu(x).requires_grad_(True)
+    y = upfirdn2d(xg, cu(k), up=up, down=down, pad=pad)
+    assert_close(y, y_ref, 1e-5)
+    gy = seeded.tensor("ufd.gy", y.shape)
+    (gx,) = torch.autograd.grad(y, xg, cu(gy))
+    # exact adjoint: <A x, gy> == <x, A^T gy>
+    lhs = (y.detach().double().cpu() * gy.double()).sum()
+    rhs = (x.double() * gx.double().cpu()).sum()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
+def test_upfirdn2d_full_size_property():
+    """BASELINE size (32 ch at 1025^2 -> 1024^2): linearity + DC gain of the blur (kernel sums to 4)."""
+    from where2edit_amd.op import upfirdn2d
+    k = cu(O.make_kernel((1, 3, 3, 1)) * 4)
+    x = torch.randn(1, 32, 1025, 1025, device=DEV)
+    ones = torch.ones(1, 1, 1025, 1025, device=DEV)
+    y1 = upfirdn2d(ones, k, pad=(1, 1))
+    assert y1.shape[-1] == 1024
+    assert (y1[:, :, 2:-2, 2:-2] - 4.0).abs().max() < 1e-5
+    a, b = upfirdn2d(x, k, pad=(1, 1)), upfirdn2d(2.5 * x, k, pad=(1, 1))
+    assert (b - 2.5 * a).abs().max() <= 1e-5 * a.abs().max()
+
+
+# ------------------------------------------------------------------------------------------ fused_leaky_relu
+@pytest.mark.parametrize("name,shape", [("nchw", (2, 6, 5, 7)), ("seq3d", (2, 4, 6)), ("mat2d", (3, 6))])
+def test_fused_leaky_relu_golden(name, shape):
+    from where2edit_amd.op import fused_leaky_relu
+    g = golden("ops")
+    x = cu(seeded.tensor("flrelu." + name, shape)).requires_grad_(True)
+    c = shape[-1] if len(shape) == 3 else shape[1]
+    b = cu(seeded.tensor("flrelu.b." + name, (c,))).requires_grad_(True)
+    y = fused_leaky_relu(x, b)
+    gx, gb = torch.autograd.grad(y, (x, b), cu(seeded.tensor("flrelu.gy." + name, y.shape)))
+    assert_close(y, g[f"flrelu.{name}.y"], 1e-6)
+    assert_close(gx, g[f"flrelu.{name}.gx"], 1e-6)
+    assert_close(gb, g[f"flrelu.{name}.gb"], 1e-5)
+
+
+def test_fused_leaky_relu_module_and_slope():
+    from where2edit_amd.op import FusedLeakyReLU, fused_leaky_relu
+    g = golden("ops")
+    y = fused_leaky_relu(cu(seeded.tensor("flrelu.slope", (2, 3, 4, 4))), cu(seeded.tensor("flrelu.slope.b", (3,))), 0.1, 1.5)
+    assert_close(y, g["flrelu.slope.y"], 1e-6)
+    m = FusedLeakyReLU(512).to(DEV)
+    x = torch.randn(4, 512, 64, 64, device=DEV)
+    assert_close(m(x), O.fused_leaky_relu(x.cpu(), m.bias.detach().cpu()), 1e-6)
+    x = torch.randn(3, 18, 512, device=DEV)  # the 3-D branch (bias on the last dim) the mappers use
+    assert_close(m(x), O.fused_leaky_relu(x.cpu(), m.bias.detach().cpu()), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ ModulatedConv2d
+def _our_modconv(cin, cout, k, demod, up, i):
+    from where2edit_amd.stylegan2 import ModulatedConv2d
+    m = ModulatedConv2d(cin, cout, k, 512, demodulate=demod, upsample=up)
+    sd = {"weight": i["weight"], "modulation.weight": i["mod_w"], "modulation.bias": i["mod_b"]}
+    if up:
+        sd["blur.kernel"] = seeded.fir_kernel(gain=4.0)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("case", MODCONV_CASES, ids=[c[0] for c in MODCONV_CASES])
+def test_modulated_conv_golden(case):
+    g = golden("modconv")
+    name, cin, cout, k, demod, up, b, h = case
+    i = modconv_inputs(name, cin, cout, k, b, h)
+    m = _our_modconv(cin, cout, k, demod, up, i)
+    x, w = cu(i["x"]).requires_grad_(True), cu(i["w"]).requires_grad_(True)
+    y, s = m(x, w)
+    assert_close(y, g[f"{name}.y"], FWD_TOL, "y")
+    assert_close(s, g[f"{name}.s"], 1e-5, "s")
+    gx, gw = torch.autograd.grad(y, (x, w), cu(seeded.tensor(f"modconv.{name}.gy", y.shape)))
+    assert_close(gx, g[f"{name}.gx"], GRAD_TOL, "gx")
+    assert_close(gw, g[f"{name}.gw"], GRAD_TOL, "gw")
+    with torch.no_grad():
+        y2, _ = m(x.detach(), s.detach(), input_is_stylespace=True)
+    assert_close(y2, g[f"{name}.y_sspace"], FWD_TOL, "sspace")
+
+
+# every MFMA tile configuration / layer shape class of the 1024 generator, at batch 2
+STYLED_SHAPES = [
+    # cin, cout, H, up
+    (512, 512, 4, False), (512, 512, 4, True), (512, 512, 8, False), (512, 512, 16, False), (512, 512, 16, True),
+    (512, 256, 32, True), (256, 256, 64, False), (128, 128, 64, False), (128, 64, 32, True), (64, 64, 128, False),
+    (64, 32, 64, True), (32, 32, 128, False), (24, 40, 12, False), (40, 24, 6, True), (10, 6, 5, False), (6, 10, 5, True),
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,up", STYLED_SHAPES)
+def test_styled_conv_vs_oracle(cin, cout, h, up):
+    """StyledConv (fused conv+noise+bias+lrelu, blur for up) forward and all gradients vs the oracle."""
+    from where2edit_amd.stylegan2 import StyledConv
+    b = 2
+    key = f"sc.{cin}.{cout}.{h}.{int(up)}"
+    sd = {"conv.weight": seeded.tensor(key + ".w", (1, cout, cin, 3, 3)),
+          "conv.modulation.weight": seeded.tensor(key + ".mw", (cin, 512)),
+          "conv.modulation.bias": seeded.tensor(key + ".mb", (cin,), 0.05, 1.0),
+          "noise.weight": seeded.tensor(key + ".nw", (1,), 0.3),
+          "activate.bias": seeded.tensor(key + ".ab", (cout,), 0.3)}
+    if up:
+        sd["conv.blur.kernel"] = seeded.fir_kernel(gain=4.0)
+    oh = 2 * h if up else h
+    x = seeded.tensor(key + ".x", (b, cin, h, h))
+    w = seeded.tensor(key + ".wl", (b, 512))
+    noise = seeded.tensor(key + ".noise", (1, 1, oh, oh))
+    gy = seeded.tensor(key + ".gy", (b, cout, oh, oh))
+    # oracle
+    osd = {"p." + k: v.clone().requires_grad_(k in ("noise.weight", "activate.bias")) for k, v in sd.items()}
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo, so = OG.styled_conv(osd, "p", xo, wo, noise, upsample=up, input_is_stylespace=False)
+    go = torch.autograd.grad(yo, (xo, wo, osd["p.noise.weight"], osd["p.activate.bias"]), gy)
+    # HIP
+    m = StyledConv(cin, cout, 3, 512, upsample=up)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    y, s = m(xg, wg, noise=cu(noise))
+    assert_close(y, yo, FWD_TOL, "y")
+    assert_close(s, so, 1e-5, "s")
+    gg = torch.autograd.grad(y, (xg, wg, m.noise.weight, m.activate.bias), cu(gy))
+    # isolated sign flips of pre-activations within rounding of 0 are legitimate: use the L2 norm on gx
+    ex = (gg[0].cpu().double() - go[0].double()).norm() / go[0].double().norm()
+    assert ex <= GRAD_TOL, f"gx L2 rel err {ex:.3e}"
+    for a, r, what in zip(gg[1:], go[1:], ("g_latent", "g_noise_w", "g_bias")):
+        assert_close(a, r, 2e-3, what)
+
+
+@pytest.mark.parametrize("cin,h,with_skip", [(512, 4, False), (512, 8, True), (256, 64, True), (32, 256, True), (20, 6, True)])
+def test_to_rgb_vs_oracle(cin, h, with_skip):
+    from where2edit_amd.stylegan2 import ToRGB
+    b = 2
+    key = f"rgb.{cin}.{h}"
+    sd = {"bias": seeded.tensor(key + ".b", (1, 3, 1, 1), 0.3), "conv.weight": seeded.tensor(key + ".w", (1, 3, cin, 1, 1)),
+          "conv.modulation.weight": seeded.tensor(key + ".mw", (cin, 512)),
+          "conv.modulation.bias": seeded.tensor(key + ".mb", (cin,), 0.05, 1.0)}
+    if with_skip:
+        sd["upsample.kernel"] = seeded.fir_kernel(gain=4.0)
+    x = seeded.tensor(key + ".x", (b, cin, h, h))
+    w = seeded.tensor(key + ".wl", (b, 512))
+    skip = seeded.tensor(key + ".skip", (b, 3, h // 2, h // 2)) if with_skip else None
+    gy = seeded.tensor(key + ".gy", (b, 3, h, h))
+    osd = {"p." + k: v.clone() for k, v in sd.items()}
+    osd["p.bias"].requires_grad_(True)
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    so_ = skip.clone().requires_grad_(True) if with_skip else None
+    yo, _ = OG.to_rgb(osd, "p", xo, wo, so_, input_is_stylespace=False)
+    go = torch.autograd.grad(yo, [xo, wo, osd["p.bias"]] + ([so_] if with_skip else []), gy)
+    m = ToRGB(cin, 512, upsample=with_skip)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    sg = cu(skip).requires_grad_(True) if with_skip else None
+    y, _ = m(xg, wg, sg)
+    assert_close(y, yo, FWD_TOL, "y")
+    gg = torch.autograd.grad(y, [xg, wg, m.bias] + ([sg] if with_skip else []), cu(gy))
+    for a, r, what in zip(gg, go, ("gx", "g_latent", "g_bias", "g_skip")):
+        assert_close(a, r, GRAD_TOL, what)
+
+
+# ------------------------------------------------------------------------------------------ K5 / K6
+@pytest.mark.parametrize("size", [1024, 256])
+def test_clip_preprocess_golden(size):
+    from where2edit_amd.functional import clip_preprocess
+    g = golden("preproc")
+    img = cu(seeded.tensor(f"preproc.img{size}", (1, 3, size, size))).requires_grad_(True)
+    y = clip_preprocess(img)
+    assert_close(y, g[f"clip{size}.y"], 1e-5)
+    (gx,) = torch.autograd.grad(y, img, cu(seeded.tensor(f"preproc.gy{size}", y.shape)))
+    assert_close(gx[:, :, :: size // 64, :: size // 64], g[f"clip{size}.gx_strided"], 1e-5)
+    assert abs(gx.double().sum().item() - float(g[f"clip{size}.gx_sum"])) <= 1e-4 * abs(float(g[f"clip{size}.gx_sum"])) + 1e-4
+
+
+@pytest.mark.parametrize("c,h,ms", [(512, 64, 64), (3, 64, 64), (16, 32, 8), (5, 12, 5)])
+def test_mask_blend_vs_oracle(c, h, ms):
+    from where2edit_amd.functional import mask_blend
+    a, b = seeded.tensor("mb.a", (2, c, h, h)), seeded.tensor("mb.b", (2, c, h, h))
+    mask = torch.rand(2, 1, ms, ms, generator=torch.Generator().manual_seed(1))
+    ao, bo, mo = a.clone().requires_grad_(True), b.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+    yo = O.mask_blend(ao, bo, mo)
+    gy = seeded.tensor("mb.gy", yo.shape)
+    go = torch.autograd.grad(yo, (ao, bo, mo), gy)
+    ag, bg, mg = cu(a).requires_grad_(True), cu(b).requires_grad_(True), cu(mask).requires_grad_(True)
+    y = mask_blend(ag, bg, mg)
+    assert_close(y, yo, 1e-6)
+    gg = torch.autograd.grad(y, (ag, bg, mg), cu(gy))
+    assert_close(gg[0], go[0], 1e-6), assert_close(gg[1], go[1], 1e-6), assert_close(gg[2], go[2], 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ generators
+def _gen(size, cls=None):
+    from where2edit_amd.stylegan2 import Generator
+    g = (cls or Generator)(size, 512, 8)
+    g.load_state_dict(seeded.generator_state_dict(size), strict=True)
+    return g.to(DEV).eval()
+
+
+def test_generator16_golden_all_modes():
+    from where2edit_amd.attention_model import Generator as AttGenerator
+    g = golden("generator16")
+    gen = _gen(16)
+    w = cu(seeded.wplus_latents(2, 6)).requires_grad_(True)
+    img, lat, svec = gen([w], input_is_latent=True, randomize_noise=False, return_latents=True)
+    assert_close(img, g["wplus.image"], FWD_TOL, "wplus image")
+    for n, s in enumerate(svec):
+        assert_close(s, g[f"wplus.style.{n}"], 1e-5)
+    r = seeded.tensor("gen16.r", img.shape)
+    (gw,) = torch.autograd.grad((img * cu(r)).sum(), w)
+    assert_grad_close(gw, g["wplus.grad_w"], "grad_w")
+    z, z2 = cu(seeded.tensor("gen16.z", (2, 512))), cu(seeded.tensor("gen16.z2", (2, 512)))
+    tl = cu(seeded.tensor("gen16.trunc", (1, 512), 0.3))
+    with torch.no_grad():
+        assert_close(gen([z], truncation=0.7, truncation_latent=tl, randomize_noise=False)[0], g["z.image"], FWD_TOL, "z")
+        assert_close(gen([z, z2], inject_index=3, randomize_noise=False)[0], g["mix.image"], FWD_TOL, "mix")
+        assert_close(gen([w[:, 0].detach()], input_is_latent=True, randomize_noise=False)[0], g["wsingle.image"], FWD_TOL)
+        assert gen([z], randomize_noise=False)[1] is None
+    sv = [cu(g[f"wplus.style.{n}"]).requires_grad_(True) for n in range(8)]
+    img_s = gen([sv], input_is_stylespace=True, randomize_noise=False)[0]
+    assert_close(img_s, g["sspace.image"], FWD_TOL, "sspace")
+    gs = torch.autograd.grad((img_s * cu(r)).sum(), sv)
+    for n, t in enumerate(gs):
+        assert_grad_close(t, g[f"sspace.grad.{n}"], f"sspace grad {n}")
+    # attention generator: features + blends
+    ga = _gen(16, AttGenerator)
+    with torch.no_grad():
+        img_f, _, _, feats = ga([w.detach()], input_is_latent=True, randomize_noise=False, return_features=True)
+    assert_close(img_f, g["att.image"], FWD_TOL)
+    for n, f in enumerate(feats):
+        assert_close(f, g[f"att.feat.{n}"], FWD_TOL, f"feat {n}")
+    for layer in (4, 3, 5, 1):
+        w2 = (w.detach() + 0.2 * cu(seeded.tensor("gen16.dw", w.shape))).requires_grad_(True)
+        mask = cu(g[f"blend{layer}.mask"]).requires_grad_(True)
+        img_b, _, _, nf = ga([w2], input_is_latent=True, randomize_noise=False, return_features=True,
+                             attention_layer=layer, attention_map=mask, feature_map=feats)
+        assert_close(img_b, g[f"blend{layer}.image"], FWD_TOL, f"blend {layer}")
+        assert_close(nf[layer - 1], g[f"blend{layer}.feat_at"], FWD_TOL)
+        gw2, gm = torch.autograd.grad((img_b * cu(r)).sum(), (w2, mask))
+        assert_grad_close(gw2, g[f"blend{layer}.grad_w"], f"blend {layer} grad_w")
+        assert_grad_close(gm, g[f"blend{layer}.grad_mask"], f"blend {layer} grad_mask")
+    sv2 = [cu(g[f"wplus.style.{n}"]) * 1.1 for n in range(8)]
+    with torch.no_grad():
+        img_sb = ga([sv2], input_is_stylespace=True, randomize_noise=False, return_features=True, attention_layer=4,
+                    attention_map=cu(g["sblend.mask"]), feature_map=feats)[0]
+    assert_close(img_sb, g["sblend.image"], FWD_TOL)
+
+
+@pytest.mark.parametrize("size", [256, 1024])
+def test_generator_big_golden(size):
+    """config 1 shape (256) and the FFHQ-1024 generator against values captured from the reference."""
+    from where2edit_amd.attention_model import Generator as AttGenerator
+    g = golden("generator_big")
+    gen = _gen(size, AttGenerator)
+    w = cu(seeded.wplus_latents(1, gen.n_latent, salt=size))
+    with torch.no_grad():
+        img, _, svec, feats = gen([w], input_is_latent=True, randomize_noise=False, return_features=True)
+    st = size // 32
+    assert_close(img[:, :, ::st, ::st], g[f"g{size}.image_strided"], 1e-3, "image (north_star tolerance)")
+    assert abs(img.double().abs().sum().item() / float(g[f"g{size}.image_abs_sum"]) - 1) < 1e-4
+    assert [s.shape[2] for s in svec] == list(g[f"g{size}.style_dims"])
+    import numpy as np
+    for n, f in enumerate(feats):
+        pos = seeded.sample_positions(f.numel(), 32, f"g{size}.feat.{n}")
+        ref = torch.from_numpy(np.asarray(g[f"g{size}.feat_samples"][n]))
+        assert (f.reshape(-1)[cu(pos)].cpu() - ref).abs().max() <= 1e-3 * g[f"g{size}.feat_stats"][n][2], f"layer {n}"
+
+
+def test_generator64_batch_vs_oracle_with_grad():
+    size = 64
+    gen = _gen(size)
+    sd = seeded.generator_state_dict(size)
+    w = seeded.wplus_latents(3, gen.n_latent, salt=3)
+    r = seeded.tensor("g64.r", (3, 3, size, size))
+    wo = w.clone().requires_grad_(True)
+    io, _ = OG.generator_forward(sd, [wo], size=size, input_is_latent=True, randomize_noise=False)
+    (go,) = torch.autograd.grad((io * r).sum(), wo)
+    wg = cu(w).requires_grad_(True)
+    ig, _ = gen([wg], input_is_latent=True, randomize_noise=False)
+    assert_close(ig, io, FWD_TOL, "image")
+    (gg,) = torch.autograd.grad((ig * cu(r)).sum(), wg)
+    assert_grad_close(gg, go, "grad_w")
+    # random per-sample noise path (randomize_noise=True): same ops unfused, just has to run and differ
+    with torch.no_grad():
+        a = gen([cu(w)], input_is_latent=True, randomize_noise=True)[0]
+    assert a.shape == ig.shape and torch.isfinite(a).all() and rel_err(a, ig.detach()) > 1e-4
+
+
+def test_cpu_tensor_is_refused():
+    from where2edit_amd.op import upfirdn2d
+    with pytest.raises(RuntimeError, match="GPU only"):
+        upfirdn2d(torch.randn(1, 1, 8, 8), torch.ones(2, 2))

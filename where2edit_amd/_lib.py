@@ -1,0 +1,82 @@
+"""ctypes binding of libw2e.so (include/w2e.h).  This is the ONLY door to compute for the hot path:
+if the library is missing or a tensor is not on an MI355X the ops raise -- there is no CPU or
+eager-PyTorch fallback (the CPU restatement lives in oracle/ and is test-only)."""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+_PROTOS = {
+    "w2e_version": (_I, []),
+    "w2e_last_error": (ctypes.c_char_p, []),
+    "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
+    "w2e_bias_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
+    "w2e_bias_act_bwd": (_I, [_P, _P, _P, _L, _F, _F, _P]),
+    "w2e_bias_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
+    "w2e_conv_pack": (_I, [_P, _P, _I, _I, _F, _I, _I, _P]),
+    "w2e_modconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "w2e_torgb_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_torgb_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_clip_preproc_fwd": (_I, [_P, _P, _L, _I, _P]),
+    "w2e_clip_preproc_bwd": (_I, [_P, _P, _L, _I, _P]),
+    "w2e_mask_blend_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "w2e_mask_blend_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libw2e.so (built in-tree by where2edit_amd.build).  Raises if it does not exist."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: run `python -m where2edit_amd.build` (hipcc, gfx950). "
+                               "where2edit_amd has no fallback path without its HIP library.")
+        lib = ctypes.CDLL(path)  # torch is already imported: libamdhip64.so.7 resolves to the runtime torch uses
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        from . import _lib_vit  # noqa: F401  (registers the ViT entry points when present)
+        _lib_vit.declare(lib)
+        if lib.w2e_version() != 1:
+            raise RuntimeError("libw2e.so version mismatch")
+        _lib = lib
+    return _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("where2edit_amd ops run on the GPU only (got a CPU tensor); the CPU restatement "
+                           "is oracle/, for tests")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"where2edit_amd kernels are fp32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError("internal: non-contiguous tensor passed to a kernel")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.w2e_last_error().decode()}")

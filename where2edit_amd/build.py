@@ -1,0 +1,62 @@
+"""Builds libw2e.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m where2edit_amd.build [--force]
+
+Cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libw2e.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "w2e.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile every .hip under csrc/ into lib/libw2e.so.  Raises on any compiler error."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in sources():  # one hipcc per translation unit, in parallel
+        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print(f"built {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

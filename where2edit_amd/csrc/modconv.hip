@@ -1,0 +1,424 @@
+// K1: modulated 3x3 convolution as an fp32-MFMA implicit GEMM for gfx950
+// (replaces the grouped-conv arithmetic of models/stylegan2/model.py:234-276).
+//
+// Shared-weight form: y[b,o] = out_scale[b,o] * conv(Wp, in_scale[b,i] * x[b,i]) -- the per-sample
+// modulation is folded into the activation tile while it is staged into LDS, the demodulation into the
+// epilogue, so ONE packed weight tensor serves the whole batch (the reference materialises a
+// [B,Cout,Cin,3,3] weight per call).
+//
+// GEMM view per workgroup: D[o, px] += A[o, k] * B[k, px], k = (ci, tap).
+//   A = packed weights  wp[k][o]  (o contiguous)        -> LDS ws[KC*9][TN]
+//   B = activation patch with halo, pre-multiplied by in_scale -> LDS xs[KC][PH*PW]
+//   v_mfma_f32_32x32x2_f32: lane l supplies A[o = l&31][k = l>>5] and B[k = l>>5][px = l&31];
+//   the two k of one MFMA are the channel pair (2c, 2c+1) at the SAME tap, so every LDS address is
+//   lane-base + compile-time-regular offset.  D: col = l&31 = pixel, row = (r&3)+8*(r>>2)+4*(l>>5) = o,
+//   so an accumulator register stores 32 consecutive pixels of one output channel (128 B, NCHW).
+// 256 threads = 4 waves arranged WO x WP; each wave owns NOB x NPB (x 4 phases for UP) 32x32 tiles.
+// Two workgroups per CU (<= 64 KB LDS, <= 256 VGPR): one stages while the other issues MFMAs.
+//
+// Modes: SAME (stride 1, pad 1), UP (conv_transpose stride 2 as 4 output phases with 4/2/2/1 taps --
+// the zeros of the stuffed image are never multiplied), DOWN (stride-2 conv = adjoint of UP).
+#include "common.h"
+
+namespace w2e {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* x;
+    const float* wp;
+    const float* in_scale;
+    const float* out_scale;
+    float* y;
+    const float* noise;
+    const float* noise_w;
+    const float* bias;
+    const float* dot_with;
+    float* dot_out;
+    int batch, K, N;
+    int H, W;        // tile domain: output pixels for SAME/DOWN, input pixels for UP
+    int in_h, in_w;  // input tensor
+    int out_h, out_w;
+    int th, tw, tw_log2;
+    int tiles_x, tiles_y, tiles_n;
+    int ph, pw, plane;
+    unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
+};
+
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
+
+template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
+__global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
+    constexpr int TN = 32 * NOB * WO;
+    constexpr int NPH = (MODE == W2E_CONV_UP) ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ws = smem;                 // [KC*9][TN]
+    float* xs = smem + KC * 9 * TN;   // [KC][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int wo = wave / WP, wpx = wave % WP;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    bid /= p.tiles_y;
+    const int b = bid % p.batch;
+    const int nt = bid / p.batch;
+    const int n0 = nt * TN;
+    const int r0 = ty * p.th, c0 = tx * p.tw;
+
+    // per-lane LDS base of each of the wave's NPB pixel blocks (pixel coordinates are recomputed in the
+    // epilogue instead of being kept live across the MFMA loop)
+    int base[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int m = (wpx * NPB + pb) * 32 + j;
+        const int ly = m >> p.tw_log2, lx = m & (p.tw - 1);
+        const bool ok = ly < p.th && r0 + ly < p.H && c0 + lx < p.W;
+        int off;
+        if (MODE == W2E_CONV_SAME) off = ly * p.pw + lx;            // patch origin (r0-1, c0-1); tap (a,b): +a*pw+b
+        else if (MODE == W2E_CONV_UP) off = (ly + 1) * p.pw + lx + 1;  // same origin; tap: -(a>>1)*pw-(b>>1)
+        else off = 2 * ly * p.pw + 2 * lx;                          // origin (2r0, 2c0); tap: +a*pw+b
+        if (!ok) off = (MODE == W2E_CONV_UP) ? p.pw + 1 : 0;
+        base[pb] = half * p.plane + off;
+    }
+    const int a_base = half * 9 * TN + wo * NOB * 32 + j;
+
+    f32x16 acc[NOB][NPB][NPH];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int q = 0; q < NPH; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ob][pb][q][r] = 0.f;
+
+    const int64_t in_plane = (int64_t)p.in_h * p.in_w;
+    const int patch = p.ph * p.pw;
+    const int oy0 = (MODE == W2E_CONV_DOWN) ? 2 * r0 : r0 - 1;
+    const int ox0 = (MODE == W2E_CONV_DOWN) ? 2 * c0 : c0 - 1;
+    const bool wvec = (p.N & 3) == 0;
+
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        __syncthreads();  // everyone finished reading the previous chunk
+        // ---- stage the weight chunk: rows (k0*9 .. +KC*9) x cols (n0 .. +TN)
+        if (wvec) {
+            constexpr int Q = KC * 9 * TN / 4;
+            for (int q = tid; q < Q; q += 256) {
+                const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
+                const int kr = k0 * 9 + r, n = n0 + c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kr < p.K * 9 && n < p.N) v = *reinterpret_cast<const float4*>(p.wp + (int64_t)kr * p.N + n);
+                *reinterpret_cast<float4*>(ws + r * TN + c4) = v;
+            }
+        } else {
+            for (int q = tid; q < KC * 9 * TN; q += 256) {
+                const int r = q / TN, c = q % TN;
+                const int kr = k0 * 9 + r, n = n0 + c;
+                ws[q] = (kr < p.K * 9 && n < p.N) ? p.wp[(int64_t)kr * p.N + n] : 0.f;
+            }
+        }
+        // ---- stage the activation patch (with halo), modulated on the way in
+        float sc[KC];
+#pragma unroll
+        for (int ci = 0; ci < KC; ++ci)
+            sc[ci] = (k0 + ci < p.K) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + k0 + ci] : 1.f) : 0.f;
+        const float* xb = p.x + ((int64_t)b * p.K + k0) * in_plane;
+        for (int idx = tid; idx < patch; idx += 256) {
+            const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
+            const int px = idx - py * p.pw;
+            const int iy = oy0 + py, ix = ox0 + px;
+            const bool inb = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            const float* src = xb + (int64_t)iy * p.in_w + ix;
+            float v[KC];
+#pragma unroll
+            for (int ci = 0; ci < KC; ++ci) v[ci] = (inb && k0 + ci < p.K) ? src[ci * in_plane] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < KC; ++ci) xs[ci * p.plane + idx] = v[ci] * sc[ci];
+        }
+        __syncthreads();
+        // ---- MFMA over the chunk: channel pairs x taps.  Big register tiles keep the pair loop rolled
+        // (72+ MFMAs per iteration already hide the LDS latency; unrolling only adds VGPR pressure).
+        constexpr int UNR = (NOB * NPB * NPH >= 8) ? 1 : KC / 2;
+#pragma unroll UNR
+        for (int c2 = 0; c2 < KC / 2; ++c2) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ta = tap / 3, tb = tap % 3;
+                float av[NOB], bv[NPB];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (c2 * 18 + tap) * TN + ob * 32];
+                int toff;
+                if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * p.pw - (tb >> 1);
+                else toff = ta * p.pw + tb;
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) bv[pb] = xs[base[pb] + c2 * 2 * p.plane + toff];
+                const int q = (MODE == W2E_CONV_UP) ? ((ta & 1) * 2 + (tb & 1)) : 0;
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int pb = 0; pb < NPB; ++pb)
+                        acc[ob][pb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], bv[pb], acc[ob][pb][q], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue
+    const float nw = (EPI == EPI_ACT && p.noise) ? p.noise_w[0] : 0.f;
+    float* red = smem;  // EPI_DOT: TN partial sums (reuses the weight tile after a barrier)
+    if (EPI == EPI_DOT) {
+        __syncthreads();
+        if (tid < TN) red[tid] = 0.f;
+        __syncthreads();
+    }
+    int gy[NPB], gx[NPB];
+    bool valid[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        const int m = (wpx * NPB + pb) * 32 + j;
+        const int ly = m >> p.tw_log2, lx = m & (p.tw - 1);
+        gy[pb] = r0 + ly;
+        gx[pb] = c0 + lx;
+        valid[pb] = ly < p.th && gy[pb] < p.H && gx[pb] < p.W;
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ol = (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int o = n0 + ol;
+            const bool ov = o < p.N;
+            const float os = (ov && p.out_scale) ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
+            const float bs = (EPI == EPI_ACT && ov && p.bias) ? p.bias[o] : 0.f;
+            float dsum = 0.f;
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                if (!(ov && valid[pb])) continue;
+#pragma unroll
+                for (int q = 0; q < NPH; ++q) {
+                    float v = acc[ob][pb][q][r];
+                    int64_t oi;
+                    if (MODE == W2E_CONV_UP) {
+                        const int Y = 2 * gy[pb] + (q >> 1), X = 2 * gx[pb] + (q & 1);
+                        oi = (((int64_t)b * p.N + o) * p.out_h + Y) * p.out_w + X;
+                    } else {
+                        oi = (((int64_t)b * p.N + o) * p.out_h + gy[pb]) * p.out_w + gx[pb];
+                    }
+                    if (EPI == EPI_DOT) dsum += v * p.dot_with[oi];
+                    v *= os;
+                    if (EPI == EPI_ACT) {
+                        v += bs + (p.noise ? nw * p.noise[(int64_t)gy[pb] * p.out_w + gx[pb]] : 0.f);
+                        v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
+                    }
+                    p.y[oi] = v;
+                }
+            }
+            if (EPI == EPI_DOT) {
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);  // within each 32-lane half
+                if (j == 0 && ov) atomicAdd(&red[ol], dsum);
+            }
+        }
+    }
+    if (EPI == EPI_DOT) {
+        __syncthreads();
+        if (tid < TN && n0 + tid < p.N) atomicAdd(&p.dot_out[(int64_t)b * p.N + n0 + tid], red[tid]);
+    }
+}
+
+// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the
+// a=2 / b=2 taps reach them.  O((H+W) * K * N) work -- plain FMA, lanes over output channels.
+__global__ void upconv_border_kernel(ConvParams p) {
+    const int OH = 2 * p.H + 1, OW = 2 * p.W + 1;
+    const int border = OW + OH - 1;
+    const int64_t total = (int64_t)p.batch * border * p.N;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t in_plane = (int64_t)p.H * p.W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int o = (int)(e % p.N);
+        const int be = (int)((e / p.N) % border);
+        const int b = (int)(e / ((int64_t)p.N * border));
+        int Y, X;
+        if (be < OW) Y = OH - 1, X = be;
+        else Y = be - OW, X = OW - 1;
+        float acc = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            if (((Y - a) & 1) || Y - a < 0) continue;
+            const int u = (Y - a) >> 1;
+            if (u >= p.H) continue;
+            for (int bb = 0; bb < 3; ++bb) {
+                if (((X - bb) & 1) || X - bb < 0) continue;
+                const int v = (X - bb) >> 1;
+                if (v >= p.W) continue;
+                const float* xp = p.x + (int64_t)b * p.K * in_plane + (int64_t)u * p.W + v;
+                const float* wq = p.wp + (int64_t)(a * 3 + bb) * p.N + o;
+                for (int i = 0; i < p.K; ++i) {
+                    const float s = p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f;
+                    acc += wq[(int64_t)i * 9 * p.N] * (s * xp[i * in_plane]);
+                }
+            }
+        }
+        if (p.out_scale) acc *= p.out_scale[(int64_t)b * p.N + o];
+        p.y[(((int64_t)b * p.N + o) * OH + Y) * OW + X] = acc;
+    }
+}
+
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, float scale,
+                                 int transpose, int flip) {
+    const int64_t total = (int64_t)cout * cin * 9;
+    const int Kd = transpose ? cout : cin, Nd = transpose ? cin : cout;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e % Nd);
+        const int tap = (int)((e / Nd) % 9);
+        const int k = (int)(e / ((int64_t)Nd * 9));
+        const int o = transpose ? k : n, i = transpose ? n : k;
+        const int st = flip ? 8 - tap : tap;
+        wp[e] = scale * w[((int64_t)o * cin + i) * 9 + st];
+        (void)Kd;
+    }
+}
+
+struct TileCfg {
+    int nob, npb, wo, wp;
+};
+
+template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
+static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC><<<grid, 256, lds, s>>>(p);
+}
+
+template <int MODE, int EPI, int KC>
+static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    if constexpr (MODE == W2E_CONV_UP) {
+        switch (cfg) {
+            case 0: launch_cfg<MODE, EPI, 2, 1, 2, 2, KC>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 1, 1, 4, KC>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 2, 1, 4, KC>(p, grid, lds, s); return true;
+            case 3: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
+            case 4: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
+        }
+    } else {
+        switch (cfg) {
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 2, KC>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 4, KC>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 8, 1, 4, KC>(p, grid, lds, s); return true;
+            case 3: launch_cfg<MODE, EPI, 1, 2, 2, 2, KC>(p, grid, lds, s); return true;
+            case 4: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
+            case 5: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
+        }
+    }
+    return false;
+}
+
+static const TileCfg kCfgStd[] = {{2, 4, 2, 2}, {2, 4, 1, 4}, {1, 8, 1, 4}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}};
+static const TileCfg kCfgUp[] = {{2, 1, 2, 2}, {2, 1, 1, 4}, {1, 2, 1, 4}, {1, 1, 2, 2}, {1, 1, 4, 1}};
+
+static int next_pow2(int v) {
+    int r = 1;
+    while (r < v) r <<= 1;
+    return r;
+}
+
+}  // namespace w2e
+
+using namespace w2e;
+
+extern "C" int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, float scale, int transpose, int flip,
+                             void* stream) {
+    W2E_REQUIRE(weight && wp, "conv_pack: null tensor");
+    W2E_REQUIRE(cout > 0 && cin > 0, "conv_pack: bad dims");
+    const int64_t total = (int64_t)cout * cin * 9;
+    conv_pack_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(weight, wp, cout, cin, scale, transpose,
+                                                                             flip);
+    W2E_LAUNCH_CHECK("conv_pack");
+    return 0;
+}
+
+extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                              float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
+                              const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
+                              void* stream) {
+    W2E_REQUIRE(mode >= 0 && mode <= 2, "modconv3x3: bad mode %d", mode);
+    W2E_REQUIRE(x && wp && y, "modconv3x3: null tensor");
+    W2E_REQUIRE(batch >= 0 && k_ch > 0 && n_ch > 0 && h > 0 && w > 0, "modconv3x3: bad dims");
+    W2E_REQUIRE(!(act && mode != W2E_CONV_SAME), "modconv3x3: fused activation only in SAME mode");
+    W2E_REQUIRE(!(dot_with && (act || mode == W2E_CONV_UP)), "modconv3x3: dot epilogue only without act, not in UP mode");
+    W2E_REQUIRE((dot_with == nullptr) == (dot_out == nullptr), "modconv3x3: dot_with and dot_out go together");
+    W2E_REQUIRE(!noise || noise_w, "modconv3x3: noise without noise_w");
+    if (batch == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+
+    ConvParams p{};
+    p.x = x, p.wp = wp, p.in_scale = in_scale, p.out_scale = out_scale, p.y = y;
+    p.noise = noise, p.noise_w = noise_w, p.bias = bias, p.dot_with = dot_with, p.dot_out = dot_out;
+    p.batch = batch, p.K = k_ch, p.N = n_ch, p.H = h, p.W = w;
+    if (mode == W2E_CONV_SAME) p.in_h = h, p.in_w = w, p.out_h = h, p.out_w = w;
+    else if (mode == W2E_CONV_UP) p.in_h = h, p.in_w = w, p.out_h = 2 * h + 1, p.out_w = 2 * w + 1;
+    else p.in_h = 2 * h + 1, p.in_w = 2 * w + 1, p.out_h = h, p.out_w = w;
+
+    // ---- pick the tile configuration with a small cost model: a "round" is one workgroup per CU; a
+    // workgroup's time is its per-wave MFMA chain (64 cycles per 32x32x2) plus part of its staging.
+    const bool up = mode == W2E_CONV_UP;
+    const TileCfg* cfgs = up ? kCfgUp : kCfgStd;
+    const int ncfg = up ? 5 : 6;
+    const int kc = mode == W2E_CONV_DOWN ? 4 : 8;
+    const int wp2 = next_pow2(w);
+    int best = -1;
+    double best_cost = 0.0;
+    for (int c = 0; c < ncfg; ++c) {
+        const int tn = 32 * cfgs[c].nob * cfgs[c].wo, tm = 32 * cfgs[c].npb * cfgs[c].wp;
+        const int tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
+        const int th = tm / tw;
+        if (th < 1) continue;
+        const int ph = mode == W2E_CONV_SAME ? th + 2 : (up ? th + 1 : 2 * th + 1);
+        const int pw = mode == W2E_CONV_SAME ? tw + 2 : (up ? tw + 1 : 2 * tw + 1);
+        if (sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw) > 64 * 1024) continue;
+        const double wgs = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
+        const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;
+        const double t_mfma = (double)cfgs[c].nob * cfgs[c].npb * (up ? 4.0 : 1.0) * (k_ch / 2.0) * (up ? 2.25 : 9.0) * 64.0;
+        const double t_stage = (double)ceil_div(k_ch, kc) * 2500.0;
+        const double cost = rounds * (t_mfma + 0.5 * t_stage) + (wgs <= 256.0 ? 0.5 * t_stage : 0.0);
+        if (best < 0 || cost < best_cost * 0.98) best = c, best_cost = cost;
+    }
+    W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
+    const TileCfg cfg = cfgs[best];
+    const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * cfg.npb * cfg.wp;
+    p.tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
+    p.th = tm / p.tw;
+    p.tw_log2 = 0;
+    while ((1 << p.tw_log2) < p.tw) ++p.tw_log2;
+    p.tiles_x = (int)ceil_div(w, p.tw), p.tiles_y = (int)ceil_div(h, p.th), p.tiles_n = (int)ceil_div(n_ch, tn);
+    if (mode == W2E_CONV_SAME) p.ph = p.th + 2, p.pw = p.tw + 2;
+    else if (up) p.ph = p.th + 1, p.pw = p.tw + 1;
+    else p.ph = 2 * p.th + 1, p.pw = 2 * p.tw + 1;
+    p.plane = p.ph * p.pw;
+    p.pw_magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)p.pw + 1);
+    W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
+    const size_t lds = sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
+    W2E_REQUIRE(lds <= 64 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
+    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch;
+    W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
+
+    bool ok = false;
+    if (mode == W2E_CONV_SAME) {
+        if (act) ok = launch_mode<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
+        else if (dot_with) ok = launch_mode<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
+        else ok = launch_mode<W2E_CONV_SAME, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+    } else if (up) {
+        ok = launch_mode<W2E_CONV_UP, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+    } else {
+        if (dot_with) ok = launch_mode<W2E_CONV_DOWN, EPI_DOT, 4>(best, p, (int)grid, lds, s);
+        else ok = launch_mode<W2E_CONV_DOWN, EPI_PLAIN, 4>(best, p, (int)grid, lds, s);
+    }
+    W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
+    W2E_LAUNCH_CHECK("modconv3x3");
+    if (up) {
+        const int64_t total = (int64_t)batch * (2 * w + 1 + 2 * h) * n_ch;
+        upconv_border_kernel<<<stream_grid(total, 256), 256, 0, s>>>(p);
+        W2E_LAUNCH_CHECK("modconv3x3 border");
+    }
+    return 0;
+}

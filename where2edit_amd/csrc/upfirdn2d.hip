@@ -1,0 +1,154 @@
+// K2: upfirdn2d for gfx950 (replaces models/stylegan2/op/upfirdn2d.py:11-60).
+//
+// Two kernels:
+//   * upfirdn_tile_kernel  -- up=1, down=1 (the 8 Blur calls per forward, the HBM-heavy case:
+//     134 MB in + 134 MB out per image at 1024^2).  64x16 output tile per 256-thread block, the
+//     (16+kh-1) x (64+kw-1) input tile staged once in LDS, 4 outputs per thread, float4 stores,
+//     optional fused demod/noise/bias/LeakyReLU epilogue so the activation is written once.
+//   * upfirdn_generic_kernel -- any up/down/pad/flip (RGB skip up-sampling, Downsample, adjoints).
+#include "common.h"
+
+namespace w2e {
+
+constexpr int MAXK = 16;
+
+struct UpfirdnParams {
+    const float* x;
+    const float* kern;
+    float* y;
+    int64_t planes;
+    int in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip;
+    int act;
+    const float* out_scale;
+    const float* noise;
+    const float* noise_w;
+    const float* bias;
+    int channels;
+    float slope, gain;
+};
+
+__device__ __forceinline__ float epilogue(const UpfirdnParams& p, float v, int64_t plane, int oy, int ox, float nw) {
+    if (!p.act) return v;
+    if (p.out_scale) v *= p.out_scale[plane];
+    if (p.noise) v += nw * p.noise[(int64_t)oy * p.out_w + ox];
+    if (p.bias) v += p.bias[plane % p.channels];
+    return (v > 0.f ? v : v * p.slope) * p.gain;
+}
+
+constexpr int TW = 64, TH = 16;
+
+__global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* kbuf = smem;            // kh*kw taps, already oriented for correlation
+    float* tile = smem + MAXK * MAXK;
+    const int pw = TW + p.kw - 1, ph = TH + p.kh - 1;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.kh * p.kw; i += 256) {
+        const int ky = i / p.kw, kx = i % p.kw;
+        kbuf[i] = p.flip ? p.kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : p.kern[i];
+    }
+    const float nw = (p.act && p.noise) ? p.noise_w[0] : 0.f;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * p.planes;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x);
+        const int ty = (int)((t / tiles_x) % tiles_y);
+        const int64_t plane = t / ((int64_t)tiles_x * tiles_y);
+        const float* src = p.x + plane * (int64_t)p.in_h * p.in_w;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
+        __syncthreads();  // previous iteration's readers are done (also orders the kbuf fill)
+        for (int i = tid; i < ph * pw; i += 256) {
+            const int r = i / pw, c = i - r * pw;
+            const int iy = iy0 + r, ix = ix0 + c;
+            tile[i] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? src[(int64_t)iy * p.in_w + ix] : 0.f;
+        }
+        __syncthreads();
+        const int ly = tid >> 4, lx = (tid & 15) << 2;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < p.kh; ++ky) {
+            const float* row = tile + (ly + ky) * pw + lx;
+            for (int kx = 0; kx < p.kw; ++kx) {
+                const float k = kbuf[ky * p.kw + kx];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += k * row[kx + j];
+            }
+        }
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        if (oy < p.out_h && ox < p.out_w) {
+            float* dst = p.y + (plane * p.out_h + oy) * (int64_t)p.out_w + ox;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = epilogue(p, acc[j], plane, oy, ox + j < p.out_w ? ox + j : ox, nw);
+            if (ox + 3 < p.out_w && (p.out_w & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < p.out_w) dst[j] = acc[j];
+            }
+        }
+    }
+}
+
+__global__ void upfirdn_generic_kernel(UpfirdnParams p, int64_t total) {
+    __shared__ float kbuf[MAXK * MAXK];
+    for (int i = threadIdx.x; i < p.kh * p.kw; i += blockDim.x) {
+        const int ky = i / p.kw, kx = i % p.kw;
+        kbuf[i] = p.flip ? p.kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : p.kern[i];
+    }
+    __syncthreads();
+    const float nw = (p.act && p.noise) ? p.noise_w[0] : 0.f;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int ox = (int)(e % p.out_w), oy = (int)((e / p.out_w) % p.out_h);
+        const int64_t plane = e / ((int64_t)p.out_w * p.out_h);
+        const float* src = p.x + plane * (int64_t)p.in_h * p.in_w;
+        float acc = 0.f;
+        for (int ky = 0; ky < p.kh; ++ky) {
+            const int zy = oy * p.down + ky - p.pad_y0;  // row in the zero-stuffed image
+            if (zy < 0 || zy % p.up != 0) continue;
+            const int iy = zy / p.up;
+            if (iy >= p.in_h) continue;
+            for (int kx = 0; kx < p.kw; ++kx) {
+                const int zx = ox * p.down + kx - p.pad_x0;
+                if (zx < 0 || zx % p.up != 0) continue;
+                const int ix = zx / p.up;
+                if (ix >= p.in_w) continue;
+                acc += kbuf[ky * p.kw + kx] * src[(int64_t)iy * p.in_w + ix];
+            }
+        }
+        p.y[e] = epilogue(p, acc, plane, oy, ox, nw);
+    }
+}
+
+}  // namespace w2e
+
+using namespace w2e;
+
+extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, int in_h, int in_w, int out_h,
+                             int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int act,
+                             const float* out_scale, const float* noise, const float* noise_w, const float* bias,
+                             int channels, float slope, float gain, void* stream) {
+    W2E_REQUIRE(x && kern && y, "upfirdn2d: null tensor");
+    W2E_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && out_h >= 0 && out_w >= 0, "upfirdn2d: bad sizes");
+    W2E_REQUIRE(kh >= 1 && kw >= 1 && kh <= MAXK && kw <= MAXK, "upfirdn2d: kernel %dx%d unsupported (max %d)", kh, kw,
+                MAXK);
+    W2E_REQUIRE(up >= 1 && down >= 1, "upfirdn2d: up/down must be >= 1");
+    W2E_REQUIRE(!noise || noise_w, "upfirdn2d: noise without noise_w");
+    W2E_REQUIRE(!act || !bias || channels > 0, "upfirdn2d: bias needs channels");
+    const int64_t total = planes * out_h * out_w;
+    if (total == 0) return 0;
+    UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip,
+                    act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain};
+    hipStream_t s = (hipStream_t)stream;
+    if (up == 1 && down == 1 && out_w >= 16) {
+        const int tiles_x = (int)ceil_div(out_w, TW), tiles_y = (int)ceil_div(out_h, TH);
+        const int64_t n_tiles = planes * tiles_x * tiles_y;
+        const size_t lds = sizeof(float) * (MAXK * MAXK + (size_t)(TH + kh - 1) * (TW + kw - 1));
+        const int grid = (int)(n_tiles < 8192 ? n_tiles : 8192);
+        upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y);
+    } else {
+        upfirdn_generic_kernel<<<stream_grid(total, 256), 256, 0, s>>>(p, total);
+    }
+    W2E_LAUNCH_CHECK("upfirdn2d");
+    return 0;
+}

@@ -1,0 +1,309 @@
+"""torch.autograd.Functions over the C ABI of libw2e.so (include/w2e.h).
+
+PyTorch is plumbing here: it owns the device memory (outputs are torch.empty on the input's device),
+the stream (kernels are enqueued on torch's current HIP stream) and the autograd tape.  All arithmetic
+on image-sized tensors happens in the HIP kernels; torch ops are used only on [B,C]-sized style math.
+"""
+import math
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+SQRT2 = math.sqrt(2.0)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------ K2
+def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=None):
+    """One launch of w2e_upfirdn2d.  `act` = (out_scale[planes]|None, noise[HW]|None, noise_w|None, bias[C]|None)."""
+    n, c, h, w = x.shape
+    kh, kw = kernel.shape
+    y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32)
+    if act is None:
+        a = (0, None, None, None, None, 1, 0.2, SQRT2)
+    else:
+        out_scale, noise, noise_w, bias = act
+        a = (1, ptr(out_scale), ptr(noise), ptr(noise_w), ptr(bias), c, 0.2, SQRT2)
+    call("w2e_upfirdn2d", ptr(x), ptr(kernel), ptr(y), n * c, h, w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0,
+         int(flip), *a, stream_ptr())
+    return y
+
+
+class _UpFirDn2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, up, down, pad0, pad1):
+        x = _c(x)
+        kernel = _c(kernel.to(torch.float32))
+        n, c, h, w = x.shape
+        kh, kw = kernel.shape
+        out_h = (h * up + pad0 + pad1 - kh) // down + 1
+        out_w = (w * up + pad0 + pad1 - kw) // down + 1
+        if out_h <= 0 or out_w <= 0:
+            raise RuntimeError(f"upfirdn2d: empty output {out_h}x{out_w}")
+        ctx.save_for_backward(kernel)
+        ctx.geom = (h, w, up, down, pad0)
+        return _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad0, pad0, True)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (kernel,) = ctx.saved_tensors
+        h, w, up, down, pad0 = ctx.geom
+        kh, kw = kernel.shape
+        # adjoint: swap up/down, un-flipped taps, leading pad k-1-pad0, output cropped to the input size
+        gx = _upfirdn2d_raw(_c(gy), kernel, h, w, down, up, kw - 1 - pad0, kh - 1 - pad0, False)
+        return gx, None, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    """models/stylegan2/op/upfirdn2d.py:11 -- same signature and semantics, HIP kernel underneath."""
+    return _UpFirDn2d.apply(input, kernel, up, down, pad[0], pad[1])
+
+
+# ------------------------------------------------------------------------------------------ K3
+class _BiasAct(torch.autograd.Function):
+    """y = lrelu(x + bias (+ w*noise), slope) * gain with x viewed as [outer, C, inner]."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope, gain, channel_last):
+        x = _c(x)
+        bias = _c(bias)
+        if channel_last:
+            outer, ch, inner = x.numel() // x.shape[-1], x.shape[-1], 1
+        else:
+            outer, ch, inner = x.shape[0], x.shape[1], x.numel() // (x.shape[0] * x.shape[1])
+        if bias.numel() != ch:
+            raise RuntimeError(f"fused_leaky_relu: bias has {bias.numel()} entries, expected {ch}")
+        y = torch.empty_like(x)
+        call("w2e_bias_act_fwd", ptr(x), ptr(bias), None, None, ptr(y), outer, ch, inner, slope, gain, stream_ptr())
+        ctx.save_for_backward(y)
+        ctx.cfg = (slope, gain, channel_last, ch)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        slope, gain, channel_last, ch = ctx.cfg
+        gy = _c(gy)
+        gx = torch.empty_like(y)
+        call("w2e_bias_act_bwd", ptr(gy), ptr(y), ptr(gx), y.numel(), slope, gain, stream_ptr())
+        gb = None
+        if ctx.needs_input_grad[1]:
+            gb = gx.reshape(-1, ch).sum(0) if channel_last else gx.reshape(gx.shape[0], ch, -1).sum((0, 2))
+        return gx, gb, None, None, None
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """models/stylegan2/op/fused_act.py:23 -- bias on dim 1, except 3-D inputs (bias on the last dim).
+    No device move inside the op (the reference's `input.cuda()` is a bug on CPU boxes, Q1)."""
+    if input.ndim < 2:
+        raise RuntimeError("fused_leaky_relu expects at least 2 dims")
+    channel_last = input.ndim == 3 or input.ndim == 2
+    return _BiasAct.apply(input, bias, float(negative_slope), float(scale), channel_last)
+
+
+# ------------------------------------------------------------------------------------------ K1
+def conv_pack(weight, scale, transpose, flip):
+    """weight [Cout,Cin,3,3] -> [K][9][N] (w2e_conv_pack)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    wp = torch.empty(((cout if transpose else cin), 9, (cin if transpose else cout)), device=weight.device,
+                     dtype=torch.float32)
+    call("w2e_conv_pack", ptr(_c(weight.detach())), ptr(wp), cout, cin, float(scale), int(transpose), int(flip),
+         stream_ptr())
+    return wp
+
+
+MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
+
+
+def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None):
+    """One call of w2e_modconv3x3.  h,w: input size for SAME/UP, output size for DOWN."""
+    b, k = x.shape[0], x.shape[1]
+    n = wp.shape[2]
+    if wp.shape[0] != k:
+        raise RuntimeError(f"modconv: packed weight expects {wp.shape[0]} input channels, got {k}")
+    oh, ow = (h, w) if mode != MODE_UP else (2 * h + 1, 2 * w + 1)
+    y = torch.empty((b, n, oh, ow), device=x.device, dtype=torch.float32)
+    dot = torch.zeros((b, n), device=x.device, dtype=torch.float32) if dot_with is not None else None
+    noise = noise_w = bias = None
+    if act is not None:
+        noise, noise_w, bias = act
+    call("w2e_modconv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n, h, w,
+         int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
+    return y, dot
+
+
+class _StyledConv(torch.autograd.Function):
+    """Fused StyledConv: out = lrelu(d * conv(Wp, s*x) [blur] + nw*noise + bias) * sqrt2
+    (model.py:234-276, 285-290, op/fused_act.py); with fuse_act=False just d * conv(Wp, s*x) [blur]
+    (a bare ModulatedConv2d).  Differentiable in x, s, d, noise_w, bias.
+    The conv weight is treated as frozen (no weight gradient is produced -- the decoder is never
+    optimised on this path: coach.py:174-180 optimises net.mapper only)."""
+
+    @staticmethod
+    def forward(ctx, x, s, d, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act):
+        x, s = _c(x), _c(s)
+        d = _c(d) if d is not None else None
+        b, cin, h, w = x.shape
+        wp_f, wp_b = packs
+        act = (noise, noise_w, bias) if fuse_act else None
+        if upsample:
+            t, _ = _modconv_raw(MODE_UP, x, wp_f, s, d, h, w)
+            out = _upfirdn2d_raw(t, blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
+                                 act=((None,) + act) if fuse_act else None)
+        else:
+            out, _ = _modconv_raw(MODE_SAME, x, wp_f, s, d, h, w, act=act)
+        ctx.save_for_backward(x, s, d, noise, noise_w, bias, out, wp_b, blur_kernel)
+        ctx.cfg = (upsample, fuse_act)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, s, d, noise, noise_w, bias, out, wp_b, blur_kernel = ctx.saved_tensors
+        upsample, fuse_act = ctx.cfg
+        b, cin, h, w = x.shape
+        cout, oh, ow = out.shape[1], out.shape[2], out.shape[3]
+        gout = _c(gout)
+        g_bias = g_nw = None
+        if fuse_act:
+            gpre = torch.empty_like(out)
+            sums = torch.empty((b, cout, 3), device=x.device, dtype=torch.float32)
+            call("w2e_bias_act_bwd_reduce", ptr(gout), ptr(out), ptr(noise), ptr(gpre), ptr(sums), b, cout, oh * ow,
+                 0.2, SQRT2, stream_ptr())
+            s1, s2, s3 = sums[..., 0], sums[..., 1], sums[..., 2]
+            nw = noise_w if noise is not None else None
+            # sum_p gpre * (d*z) with d*z = pre - nw*noise - bias
+            dz = s1 - (nw * s2 if nw is not None else 0) - (bias.view(1, -1) * s3 if bias is not None else 0)
+            g_bias = s3.sum(0) if bias is not None else None
+            g_nw = s2.sum().reshape(1) if nw is not None else None
+        else:
+            gpre = gout
+            dz = (gout * out).sum((2, 3)) if d is not None else None
+        gd = dz / d if d is not None else None
+        if upsample:
+            # adjoint of Blur(pad=(1,1)) back onto the (2h+1)x(2w+1) transposed-conv grid, then the
+            # stride-2 conv that is the adjoint of conv_transpose2d
+            gt = _upfirdn2d_raw(gpre, blur_kernel, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
+            gx, gs = _modconv_raw(MODE_DOWN, gt, wp_b, d, s, h, w, dot_with=x)
+        else:
+            gx, gs = _modconv_raw(MODE_SAME, gpre, wp_b, d, s, h, w, dot_with=x)
+        return gx, gs, gd, None, g_nw, g_bias, None, None, None, None
+
+
+def styled_conv(x, s, d, noise, noise_w, bias, packs, blur_kernel, upsample):
+    return _StyledConv.apply(x, s, d, noise, noise_w, bias, packs, blur_kernel, upsample, True)
+
+
+def modconv(x, s, d, packs, blur_kernel, upsample):
+    """Bare ModulatedConv2d (3x3): d * conv(Wp, s*x), with the FIR blur for the up-sampling variant."""
+    return _StyledConv.apply(x, s, d, None, None, None, packs, blur_kernel, upsample, False)
+
+
+def modconv_down_plain(x, s, d, wp_f, h, w):
+    """Forward-only stride-2 conv on a (2h+1)x(2w+1) input."""
+    y, _ = _modconv_raw(MODE_DOWN, _c(x), wp_f, _c(s) if s is not None else None, _c(d) if d is not None else None, h, w)
+    return y
+
+
+# ------------------------------------------------------------------------------------------ K1r
+class _ToRGB(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wmod, bias, skip, upk):
+        x, wmod = _c(x), _c(wmod)
+        b, cin, h, w = x.shape
+        y = torch.empty((b, 3, h, w), device=x.device, dtype=torch.float32)
+        skip_c = _c(skip) if skip is not None else None
+        bias_c = _c(bias.reshape(-1)) if bias is not None else None
+        call("w2e_torgb_fwd", ptr(x), ptr(wmod), ptr(bias_c), ptr(skip_c), ptr(upk) if skip is not None else None,
+             ptr(y), b, cin, h, w, stream_ptr())
+        ctx.save_for_backward(x, wmod, upk if skip is not None else None)
+        ctx.has = (bias is not None, skip is not None, tuple(bias.shape) if bias is not None else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, wmod, upk = ctx.saved_tensors
+        has_bias, has_skip, bias_shape = ctx.has
+        gy = _c(gy)
+        b, cin, h, w = x.shape
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(wmod)
+        call("w2e_torgb_bwd", ptr(x), ptr(wmod), ptr(gy), ptr(gx), ptr(gw), b, cin, h, w, stream_ptr())
+        gb = gy.sum((0, 2, 3)).reshape(bias_shape) if has_bias else None
+        gskip = None
+        if has_skip:  # adjoint of Upsample(up=2, pad=(2,1)): down=2, un-flipped taps, leading pad 4-1-2
+            gskip = _upfirdn2d_raw(gy, upk, h // 2, w // 2, 1, 2, 1, 1, False)
+        return gx, gw, gb, gskip, None
+
+
+def to_rgb(x, wmod, bias, skip, upk):
+    """y = sum_i wmod[b,c,i] x[b,i] + bias + Upsample(skip)   (model.py:353-362)."""
+    return _ToRGB.apply(x, wmod, bias, skip, upk)
+
+
+# ------------------------------------------------------------------------------------------ K5
+class _ClipPreproc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img):
+        img = _c(img)
+        n, c, h, w = img.shape
+        if h != w:
+            raise RuntimeError("clip_preprocess expects square images")
+        out = torch.empty((n, c, 224, 224), device=img.device, dtype=torch.float32)
+        call("w2e_clip_preproc_fwd", ptr(img), ptr(out), n * c, h, stream_ptr())
+        ctx.shape = img.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        n, c, h, w = ctx.shape
+        gimg = torch.empty(ctx.shape, device=gout.device, dtype=torch.float32)
+        call("w2e_clip_preproc_bwd", ptr(_c(gout)), ptr(gimg), n * c, h, stream_ptr())
+        return gimg
+
+
+def clip_preprocess(img):
+    """AvgPool2d(size//32)(Upsample(scale_factor=7)(img)) in one closed-form pass (clip_loss.py:11-12,15)."""
+    return _ClipPreproc.apply(img)
+
+
+# ------------------------------------------------------------------------------------------ K6
+class _MaskBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mask):
+        a, b, mask = _c(a), _c(b), _c(mask)
+        n, c, h, w = a.shape
+        if b.shape != a.shape or mask.shape[0] != n or mask.shape[1] != 1 or mask.shape[2] != mask.shape[3]:
+            raise RuntimeError(f"mask_blend: shapes {tuple(a.shape)} {tuple(b.shape)} {tuple(mask.shape)}")
+        out = torch.empty_like(a)
+        call("w2e_mask_blend_fwd", ptr(a), ptr(b), ptr(mask), ptr(out), n, c, h, w, mask.shape[2], stream_ptr())
+        ctx.save_for_backward(a, b, mask)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        a, b, mask = ctx.saved_tensors
+        n, c, h, w = a.shape
+        gout = _c(gout)
+        ga = torch.empty_like(a)
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        gm = torch.empty_like(mask) if ctx.needs_input_grad[2] else None
+        call("w2e_mask_blend_bwd", ptr(gout), ptr(a), ptr(b), ptr(mask), ptr(ga), ptr(gb), ptr(gm), n, c, h, w,
+             mask.shape[2], stream_ptr())
+        return ga, gb, gm
+
+
+def mask_blend(new, old, mask):
+    """m*new + (1-m)*old with m = nearest-resized mask (attention_model.py:548-549)."""
+    return _MaskBlend.apply(new, old, mask)
