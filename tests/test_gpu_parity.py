@@ -161,6 +161,10 @@ def test_styled_conv_vs_oracle(cin, cout, h, up):
     osd = {"p." + k: v.clone().requires_grad_(k in ("noise.weight", "activate.bias")) for k, v in sd.items()}
     xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     yo, so = OG.styled_conv(osd, "p", xo, wo, noise, upsample=up, input_is_stylespace=False)
+    # A pre-activation within fp32 rounding of 0 may legitimately take the other LeakyReLU slope in a
+    # different (equally valid) summation order; zero the incoming gradient there so the comparison
+    # measures arithmetic, not which side of the kink a rounding error fell on.
+    gy = gy * (yo.detach().abs() > 1e-4)
     go = torch.autograd.grad(yo, (xo, wo, osd["p.noise.weight"], osd["p.activate.bias"]), gy)
     # HIP
     m = StyledConv(cin, cout, 3, 512, upsample=up)
@@ -171,11 +175,9 @@ def test_styled_conv_vs_oracle(cin, cout, h, up):
     assert_close(y, yo, FWD_TOL, "y")
     assert_close(s, so, 1e-5, "s")
     gg = torch.autograd.grad(y, (xg, wg, m.noise.weight, m.activate.bias), cu(gy))
-    # isolated sign flips of pre-activations within rounding of 0 are legitimate: use the L2 norm on gx
-    ex = (gg[0].cpu().double() - go[0].double()).norm() / go[0].double().norm()
-    assert ex <= GRAD_TOL, f"gx L2 rel err {ex:.3e}"
+    assert_close(gg[0], go[0], GRAD_TOL, "gx")
     for a, r, what in zip(gg[1:], go[1:], ("g_latent", "g_noise_w", "g_bias")):
-        assert_close(a, r, 2e-3, what)
+        assert_close(a, r, GRAD_TOL, what)
 
 
 @pytest.mark.parametrize("cin,h,with_skip", [(512, 4, False), (512, 8, True), (256, 64, True), (32, 256, True), (20, 6, True)])
