@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1024^2 edited images/s per StyleCLIP-mapper training step (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one iteration of mapper/training/coach.py:79-92 on this rank's shard of synthetic
+FFHQ-shape W+ latents: G(w) [no grad] -> w_hat = w + 0.1 M(w) -> G(w_hat) -> CLIP loss + latent L2 ->
+backward -> (all-reduce of mapper grads) -> Ranger step.  Workload at N=1 = BASELINE configs[1]:
+FFHQ-1024 StyleGAN2 + clip_loss, batch 4.  Weak scaling: 4 latents per GPU at every N.
+Weights are random-init of the real architectures (no network for checkpoints), data is synthetic.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the ModulatedConv2d 3x3 MFMA kernel: algorithmic FLOPs / HIP-event time, vs fp32-MFMA peak
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+G_FWD_GFLOP_1024 = 148.13  # 3x3 modconv stack per image forward (ToRGB's 0.39 is not MFMA work)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def make_opts(size, batch):
+    return types.SimpleNamespace(
+        mapper_type="LevelsMapper", no_coarse_mapper=False, no_medium_mapper=False, no_fine_mapper=False,
+        work_in_stylespace=False, stylegan_size=size, checkpoint_path=None, stylegan_weights=None,
+        batch_size=batch, test_batch_size=1, learning_rate=0.5, optim_name="ranger", id_lambda=0.0, clip_lambda=1.0,
+        latent_l2_lambda=0.8, max_steps=0, description="synthetic prompt")
+
+
+def build_coach(size, batch, device, data_parallel, clip_backend):
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.coach import Coach, synthetic_tokens
+    from where2edit_amd.styleclip_mapper import StyleCLIPMapper
+    torch.manual_seed(0)  # identical replicas on every rank
+    opts = make_opts(size, batch)
+    net = StyleCLIPMapper(opts)
+    with torch.no_grad():  # the reference inits these to 0; give them values so the fused epilogue paths are live
+        for name, p in net.decoder.named_parameters():
+            if name.endswith("noise.weight") or name.endswith("activate.bias") or name.endswith("to_rgb1.bias") \
+                    or (".to_rgbs." in name and name.endswith(".bias") and p.ndim == 4):
+                p.normal_(0, 0.1)
+    clip = CLIPLoss(opts, model=CLIP(visual_backend=clip_backend))
+    coach = Coach(opts, net=net, clip_loss=clip, text_inputs=synthetic_tokens(1), device=device,
+                  data_parallel=data_parallel)
+    return coach
+
+
+@torch.no_grad()
+def synthetic_latents(gen, batch, rank):
+    """z ~ N(0,I), seed 1234+rank -> style MLP -> truncation 0.7 toward mean_latent(4096) -> W+."""
+    dev = gen.input.input.device
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    z = torch.randn(batch, 512, generator=g).to(dev)
+    gm = torch.Generator(device="cpu").manual_seed(4096)
+    mean_w = gen.style(torch.randn(4096, 512, generator=gm).to(dev)).mean(0, keepdim=True)
+    w = mean_w + 0.7 * (gen.style(z) - mean_w)
+    return w.unsqueeze(1).repeat(1, gen.n_latent, 1).contiguous()
+
+
+def cpu_baseline(size):
+    """The oracle's mapper step (oracle/step.py, a port of coach.py:79-92 on stock CPU torch ops) at batch 1
+    on this box's host cores: one full step (2 G forwards + CLIP + backward + Ranger).  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import seeded
+    from oracle import step as ostep
+    from oracle import stylegan2 as og
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gsd = seeded.generator_state_dict(size)
+    msd = {k: v.requires_grad_(True) for k, v in
+           seeded.mapper_state_dict(["course_mapping.", "medium_mapping.", "fine_mapping."]).items()}
+    csd = seeded.clip_state_dict()
+    from where2edit_amd.coach import synthetic_tokens
+    tokens = synthetic_tokens(1)
+    w = seeded.wplus_latents(1, og.n_latent(size), salt=7)
+    params = list(msd.values())
+    st = ostep.RangerState(params, lr=0.5)
+    with torch.no_grad():  # page in the weights / spin up the thread pool on a small case, untimed
+        og.generator_forward(seeded.generator_state_dict(64), [seeded.wplus_latents(1, 10)], size=64, input_is_latent=True,
+                             randomize_noise=False)
+    t0 = time.perf_counter()
+    loss, _, _, _, _ = ostep.mapper_step_loss(gsd, msd, csd, w, tokens, size=size, clip_lambda=1.0, latent_l2_lambda=0.8)
+    grads = torch.autograd.grad(loss, params)
+    st.step(params, grads)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 mapper step (2 G fwd + CLIP ViT-B/32 fwd/bwd + G bwd + Ranger), batch 1, {size}^2, "
+                      f"torch {torch.__version__} CPU ops, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="latents per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--clip-backend", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from where2edit_amd import dist as wd
+    from where2edit_amd import profiling
+    rank, world, local = wd.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = f"cuda:{local}"
+    torch.cuda.set_device(device)
+    coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend)
+    w = synthetic_latents(coach.net.decoder, args.batch, rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        coach.train_step(w)
+    barrier()
+    timer = None if args.no_kernel_timing else profiling.KernelTimer()
+    if timer is not None:
+        timer.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = coach.train_step(w)
+    barrier()
+    dt = time.perf_counter() - t0
+    if timer is not None:
+        timer.__exit__(None, None, None)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+    loss = float(last["loss"])
+    if not (loss == loss):
+        raise SystemExit("loss is NaN")
+    global_batch = args.batch * world
+    value = global_batch * args.steps / dt
+    out = {
+        "metric": "1024^2 edited images/sec per mapper step" if args.size == 1024 else f"{args.size}^2 edited images/sec per mapper step",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
+                               f"LevelsMapper, Ranger, id_lambda=0", "global_batch": global_batch,
+                   "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "final_loss": loss},
+    }
+    if timer is not None:
+        s = timer.summary()
+        calls, ms, flops = s.get("modconv3x3", (0, 0.0, 0.0))
+        if calls:
+            achieved = flops / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "w2e::modconv_kernel (fp32 MFMA 32x32x2 implicit-GEMM 3x3 modconv; "
+                               "all tile configs, fwd + dgrad)", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches": calls, "avg_launch_ms": ms / calls, "flop_per_launch": flops / calls,
+                               "share_of_step": ms / (1e3 * dt)}
+        c2, ms2, by2 = s.get("upfirdn2d", (0, 0.0, 0.0))
+        if c2:
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "w2e::upfirdn_*", "achieved": by2 / (ms2 * 1e-3) / 1e9,
+                                   "peak": 8000.0, "unit": "GB/s", "frac": by2 / (ms2 * 1e-3) / 1e9 / 8000.0,
+                                   "launches": c2, "share_of_step": ms2 / (1e3 * dt)}
+        # whole-stack figure the north_star target is quoted on: 3 G-equivalents per image per step
+        if args.size == 1024:
+            stack_tflops = 3 * G_FWD_GFLOP_1024 * 1e9 * global_batch * args.steps / dt / 1e12 / world
+            out["stack_mfma_frac_of_step"] = stack_tflops / FP32_MFMA_PEAK_TFLOPS
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

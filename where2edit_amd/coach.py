@@ -1,0 +1,152 @@
+"""mapper/training/coach.py surface, reduced to the hot path: `Coach(opts)` builds the same objects
+(net = StyleCLIPMapper, clip_loss, id_loss, latent_l2_loss, optimizer over net.mapper.parameters() only)
+and `train_step(w)` is one iteration of the reference's `train()` loop body (coach.py:79-92):
+
+    x     = G(w)                       (no grad)
+    w_hat = w + 0.1 * M(w)
+    x_hat = G(w_hat)
+    L     = id_lambda*L_id(x_hat,x) + clip_lambda*mean(CLIPLoss(x_hat,text)) + l2_lambda*MSE(w_hat,w)
+    L.backward(); [all-reduce mapper grads]; optimizer.step()
+
+TensorBoard / image grids / dataset plumbing are out of scope; `train()` iterates a latent
+tensor with the same shuffle/drop_last semantics and `checkpoint_me()` writes the reference's schema."""
+import os
+
+import torch
+from torch import nn
+
+from . import dist as w2e_dist
+from .clip_loss import CLIPLoss
+from .ranger import Ranger
+from .styleclip_mapper import StyleCLIPMapper
+
+
+class Coach:
+    def __init__(self, opts, net=None, clip_loss=None, id_loss=None, text_inputs=None, device=None, data_parallel=False):
+        self.opts = opts
+        self.global_step = 0
+        self.device = device if device is not None else "cuda:0"  # coach.py:25
+        self.opts.device = self.device
+        self.net = (net if net is not None else StyleCLIPMapper(self.opts)).to(self.device)
+        if self.opts.id_lambda > 0:
+            if id_loss is None:
+                from .id_loss import IDLoss
+                id_loss = IDLoss(self.opts)
+            self.id_loss = id_loss.to(self.device).eval()
+        if self.opts.clip_lambda > 0:
+            self.clip_loss = (clip_loss if clip_loss is not None else CLIPLoss(opts)).to(self.device)
+        if self.opts.latent_l2_lambda > 0:
+            self.latent_l2_loss = nn.MSELoss().to(self.device).eval()
+        self.optimizer = self.configure_optimizers()
+        # text tokens: the reference tokenises opts.description with OpenAI's BPE (coach.py:55); the tokenizer
+        # is not in this image, so callers pass token ids ([n_text, 77] int64) or get a fixed synthetic prompt
+        if text_inputs is None:
+            text_inputs = synthetic_tokens(1)
+        self.text_inputs = text_inputs.to(self.device)
+        self.bucket = w2e_dist.GradBucket(self.net.mapper.parameters()) if data_parallel else None
+        self.best_val_loss = None
+
+    def configure_optimizers(self):
+        params = list(self.net.mapper.parameters())  # mapper only: the decoder is never optimised (coach.py:174-180)
+        if self.opts.optim_name == "adam":
+            return torch.optim.Adam(params, lr=self.opts.learning_rate)
+        return Ranger(params, lr=self.opts.learning_rate)
+
+    def forward_pair(self, w):
+        """coach.py:80-89 (W+ and S-space branches)."""
+        dec = self.net.decoder
+        s_space = getattr(self.opts, "work_in_stylespace", False)
+        with torch.no_grad():
+            x, _ = dec([w], input_is_latent=True, randomize_noise=False, truncation=1, input_is_stylespace=s_space)
+        if s_space:
+            delta = self.net.mapper(w)
+            w_hat = [c + 0.1 * dc for c, dc in zip(w, delta)]
+            x_hat, _, w_hat = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False,
+                                  truncation=1, input_is_stylespace=True)
+        else:
+            w_hat = w + 0.1 * self.net.mapper(w)
+            x_hat, w_hat, _ = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False, truncation=1)
+        return x, x_hat, w_hat
+
+    def calc_loss(self, w, x, w_hat, x_hat):
+        """coach.py:223-245; the loss dict holds 0-dim tensors (no host sync inside the step)."""
+        loss_dict = {}
+        loss = 0.0
+        if self.opts.id_lambda > 0:
+            loss_id, sim_improvement = self.id_loss(x_hat, x)
+            loss_dict["loss_id"] = loss_id.detach()
+            loss_dict["id_improve"] = sim_improvement
+            loss = loss_id * self.opts.id_lambda
+        if self.opts.clip_lambda > 0:
+            loss_clip = self.clip_loss(x_hat, self.text_inputs).mean()
+            loss_dict["loss_clip"] = loss_clip.detach()
+            loss = loss + loss_clip * self.opts.clip_lambda
+        if self.opts.latent_l2_lambda > 0:
+            if getattr(self.opts, "work_in_stylespace", False):
+                loss_l2_latent = sum(self.latent_l2_loss(c_hat, c) for c_hat, c in zip(w_hat, w))
+            else:
+                loss_l2_latent = self.latent_l2_loss(w_hat, w)
+            loss_dict["loss_l2_latent"] = loss_l2_latent.detach()
+            loss = loss + loss_l2_latent * self.opts.latent_l2_lambda
+        loss_dict["loss"] = loss.detach()
+        return loss, loss_dict
+
+    def train_step(self, w):
+        """One mapper step on this rank's shard of latents (the unit of the headline metric)."""
+        if self.bucket is not None:
+            self.bucket.zero()
+        else:
+            self.optimizer.zero_grad()
+        x, x_hat, w_hat = self.forward_pair(w)
+        loss, loss_dict = self.calc_loss(w, x, w_hat, x_hat)
+        loss.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        self.global_step += 1
+        return loss_dict
+
+    def train(self, latents, max_steps=None, generator=None):
+        """Epochs over a [N,18,512] latent tensor: shuffle, batch_size, drop_last (coach.py:44-48,70-79)."""
+        self.net.train()
+        max_steps = max_steps if max_steps is not None else self.opts.max_steps
+        bs = self.opts.batch_size
+        log = []
+        while self.global_step < max_steps:
+            perm = torch.randperm(latents.shape[0], generator=generator)
+            for i in range(0, latents.shape[0] - bs + 1, bs):
+                if self.global_step >= max_steps:
+                    break
+                log.append(self.train_step(latents[perm[i:i + bs]].to(self.device)))
+        return log
+
+    @torch.no_grad()
+    def validate(self, latents):
+        """coach.py:122-161 without image logging: mean loss dict over held-out latents."""
+        self.net.eval()
+        agg = []
+        bs = getattr(self.opts, "test_batch_size", 1)
+        for i in range(0, min(latents.shape[0], 201 * bs) - bs + 1, bs):
+            w = latents[i:i + bs].to(self.device)
+            x, x_hat, w_hat = self.forward_pair(w)
+            _, d = self.calc_loss(w, x, w_hat, x_hat)
+            agg.append({k: float(v) for k, v in d.items()})
+        self.net.train()
+        return {k: sum(d[k] for d in agg) / len(agg) for k in agg[0]} if agg else {}
+
+    def checkpoint_me(self, path):
+        """coach.py:163-172,267-272: {'state_dict': net.state_dict(), 'opts': vars(opts)}."""
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({"state_dict": self.net.state_dict(), "opts": {k: v for k, v in vars(self.opts).items()}}, path)
+
+
+def synthetic_tokens(n_text=1, context_length=77, vocab_size=49408, seed=0):
+    """Stand-in for clip.tokenize(description): <SOT> ... <EOT> with the EOT id the highest (argmax pooling)."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.zeros(n_text, context_length, dtype=torch.int64)
+    for i in range(n_text):
+        n = 6 + i
+        t[i, 0] = vocab_size - 2
+        t[i, 1:n] = torch.randint(1, vocab_size - 2, (n - 1,), generator=g)
+        t[i, n] = vocab_size - 1
+    return t

@@ -13,11 +13,18 @@
 //   the two k of one MFMA are the channel pair (2c, 2c+1) at the SAME tap, so every LDS address is
 //   lane-base + compile-time-regular offset.  D: col = l&31 = pixel, row = (r&3)+8*(r>>2)+4*(l>>5) = o,
 //   so an accumulator register stores 32 consecutive pixels of one output channel (128 B, NCHW).
-// 256 threads = 4 waves arranged WO x WP; each wave owns NOB x NPB (x 4 phases for UP) 32x32 tiles.
-// Two workgroups per CU (<= 64 KB LDS, <= 256 VGPR): one stages while the other issues MFMAs.
+// Waves are arranged WO x WP (8 waves = 512 threads for the big tiles, 4 for the low-resolution ones); each
+// wave owns NOB x NPB 32x32 accumulator tiles.  The K loop is software-pipelined: the next chunk's global
+// loads are in flight (in registers) while the current chunk's MFMAs issue.
 //
-// Modes: SAME (stride 1, pad 1), UP (conv_transpose stride 2 as 4 output phases with 4/2/2/1 taps --
-// the zeros of the stuffed image are never multiplied), DOWN (stride-2 conv = adjoint of UP).
+// Modes: SAME (stride 1, pad 1), UP (conv_transpose stride 2, computed as its 4 output phases: a
+// workgroup owns ONE phase (blockIdx & 3) and runs only that phase's 4/2/2/1 taps, so the zeros of the
+// stuffed image are never multiplied and the weight bytes staged per MFMA equal SAME's), DOWN (stride-2
+// conv = adjoint of UP).
+#include <math.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace w2e {
@@ -47,10 +54,53 @@ struct ConvParams {
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
 
+// Upper bound of ceil(patch / threads) for a tile of `tm` pixels (the host refuses geometries beyond it).
+__host__ __device__ constexpr int max_patch_slots(int mode, int tm, int nt) {
+    return mode == W2E_CONV_DOWN ? (nt == 512 ? (tm >= 1024 ? 9 : 5) : (tm >= 256 ? 5 : (tm >= 128 ? 3 : (tm >= 64 ? 2 : 1))))
+                                 : (nt == 512 ? (tm >= 2048 ? 5 : (tm >= 1024 ? 3 : 2)) : (tm >= 256 ? 2 : 1));
+}
+
+__device__ __forceinline__ bool tap_in_phase(int tap, int phase) {
+    return ((tap / 3) & 1) == (phase >> 1) && ((tap % 3) & 1) == (phase & 1);
+}
+
+// One K-chunk of MFMAs for a wave: channel pairs x taps.  For UP, (PY,PX) is the output phase and only
+// taps with (ta&1)==PY, (tb&1)==PX exist (resolved at compile time after unrolling).
+template <int MODE, int NOB, int NPB, int KC, int TN, int PY, int PX>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float* ws, const float* xs, int a_base,
+                                           const int (&base)[NPB], int pw, int plane) {
+    constexpr int NTAPS = (MODE == W2E_CONV_UP) ? (PY ? 1 : 2) * (PX ? 1 : 2) : 9;
+    // big register tiles keep the pair loop rolled: >= 32 MFMAs per iteration already hide the LDS latency
+    constexpr int WORK = NOB * NPB * NTAPS;
+    constexpr int UNR = WORK >= 32 ? 1 : (WORK >= 16 ? 2 : KC / 2);
+#pragma unroll UNR
+    for (int c2 = 0; c2 < KC / 2; ++c2) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ta = tap / 3, tb = tap % 3;
+            if (MODE == W2E_CONV_UP && (((ta & 1) != PY) || ((tb & 1) != PX))) continue;
+            float av[NOB], bv[NPB];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (c2 * 18 + tap) * TN + ob * 32];
+            int toff;
+            if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * pw - (tb >> 1);
+            else toff = ta * pw + tb;
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) bv[pb] = xs[base[pb] + c2 * 2 * plane + toff];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb)
+                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], bv[pb], acc[ob][pb], 0, 0, 0);
+        }
+    }
+}
+
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
-__global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
+    constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
     constexpr int TN = 32 * NOB * WO;
-    constexpr int NPH = (MODE == W2E_CONV_UP) ? 4 : 1;
+    constexpr int MAXX = max_patch_slots(MODE, 32 * NPB * WP, NT);  // activation-patch elements per thread (x KC channels)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ws = smem;                 // [KC*9][TN]
     float* xs = smem + KC * 9 * TN;   // [KC][plane]
@@ -60,6 +110,10 @@ __global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
     const int wo = wave / WP, wpx = wave % WP;
 
     int bid = blockIdx.x;
+    // UP: phase-major grid, phase 0 (4 taps) first so the light phases fill the tail; (py,px) = (phase>>1, phase&1)
+    const int per_phase = gridDim.x >> 2;
+    const int phase = (MODE == W2E_CONV_UP) ? bid / per_phase : 0;
+    if (MODE == W2E_CONV_UP) bid -= phase * per_phase;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -86,15 +140,13 @@ __global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
     }
     const int a_base = half * 9 * TN + wo * NOB * 32 + j;
 
-    f32x16 acc[NOB][NPB][NPH];
+    f32x16 acc[NOB][NPB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-            for (int q = 0; q < NPH; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ob][pb][q][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[ob][pb][r] = 0.f;
 
     const int64_t in_plane = (int64_t)p.in_h * p.in_w;
     const int patch = p.ph * p.pw;
@@ -102,68 +154,93 @@ __global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
     const int ox0 = (MODE == W2E_CONV_DOWN) ? 2 * c0 : c0 - 1;
     const bool wvec = (p.N & 3) == 0;
 
-    for (int k0 = 0; k0 < p.K; k0 += KC) {
-        __syncthreads();  // everyone finished reading the previous chunk
-        // ---- stage the weight chunk: rows (k0*9 .. +KC*9) x cols (n0 .. +TN)
-        if (wvec) {
-            constexpr int Q = KC * 9 * TN / 4;
-            for (int q = tid; q < Q; q += 256) {
-                const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
-                const int kr = k0 * 9 + r, n = n0 + c4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kr < p.K * 9 && n < p.N) v = *reinterpret_cast<const float4*>(p.wp + (int64_t)kr * p.N + n);
-                *reinterpret_cast<float4*>(ws + r * TN + c4) = v;
+    // ---- software pipeline (T14 "issue early / write late"): the global loads of chunk k+1 are issued into
+    // registers right after chunk k is published to LDS and land while chunk k's MFMAs run; they are
+    // written to LDS (activations multiplied by in_scale on the way) after the barrier that retires chunk k.
+    constexpr int WQ = (KC * 9 * TN / 4 + NT - 1) / NT;  // float4 weight slots per thread
+    float4 wr[WQ];
+    float xr[MAXX][KC];
+    float sc[KC];
+
+    auto prefetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < WQ; ++t) {
+            const int q = tid + t * NT;
+            const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
+            const int kr = k0 * 9 + r, n = n0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool want = q < KC * 9 * TN / 4 && kr < p.K * 9 && (MODE != W2E_CONV_UP || tap_in_phase(r % 9, phase));
+            if (want) {
+                const float* wsrc = p.wp + (int64_t)kr * p.N + n;
+                if (wvec) {
+                    if (n < p.N) v = *reinterpret_cast<const float4*>(wsrc);
+                } else {
+                    if (n < p.N) v.x = wsrc[0];
+                    if (n + 1 < p.N) v.y = wsrc[1];
+                    if (n + 2 < p.N) v.z = wsrc[2];
+                    if (n + 3 < p.N) v.w = wsrc[3];
+                }
             }
-        } else {
-            for (int q = tid; q < KC * 9 * TN; q += 256) {
-                const int r = q / TN, c = q % TN;
-                const int kr = k0 * 9 + r, n = n0 + c;
-                ws[q] = (kr < p.K * 9 && n < p.N) ? p.wp[(int64_t)kr * p.N + n] : 0.f;
-            }
+            wr[t] = v;
         }
-        // ---- stage the activation patch (with halo), modulated on the way in
-        float sc[KC];
 #pragma unroll
         for (int ci = 0; ci < KC; ++ci)
             sc[ci] = (k0 + ci < p.K) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + k0 + ci] : 1.f) : 0.f;
         const float* xb = p.x + ((int64_t)b * p.K + k0) * in_plane;
-        for (int idx = tid; idx < patch; idx += 256) {
+#pragma unroll
+        for (int t = 0; t < MAXX; ++t) {
+            const int idx = tid + t * NT;
             const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
             const int px = idx - py * p.pw;
             const int iy = oy0 + py, ix = ox0 + px;
-            const bool inb = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            const bool inb = idx < patch && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
             const float* src = xb + (int64_t)iy * p.in_w + ix;
-            float v[KC];
 #pragma unroll
-            for (int ci = 0; ci < KC; ++ci) v[ci] = (inb && k0 + ci < p.K) ? src[ci * in_plane] : 0.f;
-#pragma unroll
-            for (int ci = 0; ci < KC; ++ci) xs[ci * p.plane + idx] = v[ci] * sc[ci];
+            for (int ci = 0; ci < KC; ++ci) xr[t][ci] = (inb && k0 + ci < p.K) ? src[ci * in_plane] : 0.f;
         }
-        __syncthreads();
-        // ---- MFMA over the chunk: channel pairs x taps.  Big register tiles keep the pair loop rolled
-        // (72+ MFMAs per iteration already hide the LDS latency; unrolling only adds VGPR pressure).
-        constexpr int UNR = (NOB * NPB * NPH >= 8) ? 1 : KC / 2;
-#pragma unroll UNR
-        for (int c2 = 0; c2 < KC / 2; ++c2) {
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ta = tap / 3, tb = tap % 3;
-                float av[NOB], bv[NPB];
+        for (int t = 0; t < WQ; ++t) {
+            const int q = tid + t * NT;
+            const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
+            if (q < KC * 9 * TN / 4 && (MODE != W2E_CONV_UP || tap_in_phase(r % 9, phase)))
+                *reinterpret_cast<float4*>(ws + r * TN + c4) = wr[t];
+        }
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (c2 * 18 + tap) * TN + ob * 32];
-                int toff;
-                if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * p.pw - (tb >> 1);
-                else toff = ta * p.pw + tb;
+        for (int t = 0; t < MAXX; ++t) {
+            const int idx = tid + t * NT;
+            if (idx < patch) {
 #pragma unroll
-                for (int pb = 0; pb < NPB; ++pb) bv[pb] = xs[base[pb] + c2 * 2 * p.plane + toff];
-                const int q = (MODE == W2E_CONV_UP) ? ((ta & 1) * 2 + (tb & 1)) : 0;
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-                    for (int pb = 0; pb < NPB; ++pb)
-                        acc[ob][pb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], bv[pb], acc[ob][pb][q], 0, 0, 0);
+                for (int ci = 0; ci < KC; ++ci) xs[ci * p.plane + idx] = xr[t][ci] * sc[ci];
             }
         }
+    };
+
+    // The K loop, instantiated once per output phase for UP (the phase is uniform per workgroup; keeping the
+    // switch OUTSIDE the loop gives each phase its own loop nest and register allocation).
+    auto k_loop = [&](auto py_c, auto px_c) __attribute__((always_inline)) {
+        constexpr int PY = decltype(py_c)::value, PX = decltype(px_c)::value;
+        prefetch(0);
+        for (int k0 = 0; k0 < p.K; k0 += KC) {
+            __syncthreads();  // everyone finished reading the previous chunk
+            commit();
+            __syncthreads();
+            if (k0 + KC < p.K) prefetch(k0 + KC);
+            mfma_chunk<MODE, NOB, NPB, KC, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (MODE == W2E_CONV_UP) {
+        switch (phase) {
+            case 0: k_loop(I0{}, I0{}); break;
+            case 1: k_loop(I0{}, I1{}); break;
+            case 2: k_loop(I1{}, I0{}); break;
+            default: k_loop(I1{}, I1{}); break;
+        }
+    } else {
+        k_loop(I0{}, I0{});
     }
 
     // ---- epilogue
@@ -197,12 +274,11 @@ __global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
                 if (!(ov && valid[pb])) continue;
-#pragma unroll
-                for (int q = 0; q < NPH; ++q) {
-                    float v = acc[ob][pb][q][r];
+                {
+                    float v = acc[ob][pb][r];
                     int64_t oi;
                     if (MODE == W2E_CONV_UP) {
-                        const int Y = 2 * gy[pb] + (q >> 1), X = 2 * gx[pb] + (q & 1);
+                        const int Y = 2 * gy[pb] + (phase >> 1), X = 2 * gx[pb] + (phase & 1);
                         oi = (((int64_t)b * p.N + o) * p.out_h + Y) * p.out_w + X;
                     } else {
                         oi = (((int64_t)b * p.N + o) * p.out_h + gy[pb]) * p.out_w + gx[pb];
@@ -229,40 +305,67 @@ __global__ __launch_bounds__(256, 2) void modconv_kernel(ConvParams p) {
     }
 }
 
-// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the
-// a=2 / b=2 taps reach them.  O((H+W) * K * N) work -- plain FMA, lanes over output channels.
-__global__ void upconv_border_kernel(ConvParams p) {
+// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the a=2
+// (row) / b=2 (column) taps reach them.  One block = 8 consecutive border elements of one image x OL output
+// channels; its 256 threads are OL channel lanes (coalesced weight reads) x KG slices of the input channels
+// (the reduction is a chain of dependent-latency loads, so it is split KG ways and unrolled), LDS-reduced.
+template <int OL>
+__global__ __launch_bounds__(256) void upconv_border_kernel(ConvParams p, int groups_row, int groups_col) {
+    constexpr int KG = 256 / OL;
+    __shared__ float red[KG][OL][8];
     const int OH = 2 * p.H + 1, OW = 2 * p.W + 1;
-    const int border = OW + OH - 1;
-    const int64_t total = (int64_t)p.batch * border * p.N;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const int groups = groups_row + groups_col;
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const bool is_row = g < groups_row;
+    const int e0 = (is_row ? g : g - groups_row) * 8;  // first X (row) or Y (column) of the group
+    const int lim = is_row ? OW : OH - 1;               // the corner belongs to the row
+    const int L = is_row ? p.W : p.H;                   // input extent along the border
     const int64_t in_plane = (int64_t)p.H * p.W;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
-        const int o = (int)(e % p.N);
-        const int be = (int)((e / p.N) % border);
-        const int b = (int)(e / ((int64_t)p.N * border));
-        int Y, X;
-        if (be < OW) Y = OH - 1, X = be;
-        else Y = be - OW, X = OW - 1;
-        float acc = 0.f;
-        for (int a = 0; a < 3; ++a) {
-            if (((Y - a) & 1) || Y - a < 0) continue;
-            const int u = (Y - a) >> 1;
-            if (u >= p.H) continue;
-            for (int bb = 0; bb < 3; ++bb) {
-                if (((X - bb) & 1) || X - bb < 0) continue;
-                const int v = (X - bb) >> 1;
-                if (v >= p.W) continue;
-                const float* xp = p.x + (int64_t)b * p.K * in_plane + (int64_t)u * p.W + v;
-                const float* wq = p.wp + (int64_t)(a * 3 + bb) * p.N + o;
-                for (int i = 0; i < p.K; ++i) {
-                    const float s = p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f;
-                    acc += wq[(int64_t)i * 9 * p.N] * (s * xp[i * in_plane]);
-                }
-            }
+    const int v0 = (e0 >> 1) - 1;                       // input positions v0 .. v0+4 feed 8 outputs
+    const int64_t stride = is_row ? 1 : p.W;
+    const int64_t fixed = is_row ? (int64_t)(p.H - 1) * p.W : (p.W - 1);
+    const int ol = threadIdx.x % OL, kg = threadIdx.x / OL;
+    const int o = blockIdx.y * OL + ol;
+    const bool ov = o < p.N;
+    // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
+    const int64_t t0 = (is_row ? 6 : 2) * (int64_t)p.N, t1 = (is_row ? 7 : 5) * (int64_t)p.N, t2 = 8 * (int64_t)p.N;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool inb[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) inb[t] = v0 + t >= 0 && v0 + t < L;
+    const int kper = (p.K + KG - 1) / KG;
+    const int i_lo = kg * kper, i_hi = (i_lo + kper < p.K) ? i_lo + kper : p.K;
+#pragma unroll 4
+    for (int i = i_lo; i < i_hi; ++i) {
+        const float s = p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f;
+        const float* xp = p.x + ((int64_t)b * p.K + i) * in_plane + fixed + (int64_t)v0 * stride;
+        float xv[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) xv[t] = inb[t] ? s * xp[t * stride] : 0.f;
+        const float* wq = p.wp + (int64_t)i * 9 * p.N + (ov ? o : 0);
+        const float w0 = wq[t0], w1 = wq[t1], w2 = wq[t2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
+            acc[2 * t] += w0 * xv[t + 1] + w2 * xv[t];
+            acc[2 * t + 1] += w1 * xv[t + 1];
         }
-        if (p.out_scale) acc *= p.out_scale[(int64_t)b * p.N + o];
-        p.y[(((int64_t)b * p.N + o) * OH + Y) * OW + X] = acc;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[kg][ol][t] = acc[t];
+    __syncthreads();
+    if (kg != 0 || !ov) return;
+#pragma unroll
+    for (int q = 1; q < KG; ++q)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] += red[q][ol][t];
+    const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
+    float* yp = p.y + ((int64_t)b * p.N + o) * OH * OW;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int e = e0 + t;
+        if (e >= lim) continue;
+        if (is_row) yp[(int64_t)(OH - 1) * OW + e] = acc[t] * os;
+        else yp[(int64_t)e * OW + OW - 1] = acc[t] * os;
     }
 }
 
@@ -287,34 +390,27 @@ struct TileCfg {
 
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
 static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s) {
-    modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC><<<grid, 256, lds, s>>>(p);
+    modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC><<<grid, 64 * WO * WP, lds, s>>>(p);
 }
 
 template <int MODE, int EPI, int KC>
 static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
-    if constexpr (MODE == W2E_CONV_UP) {
-        switch (cfg) {
-            case 0: launch_cfg<MODE, EPI, 2, 1, 2, 2, KC>(p, grid, lds, s); return true;
-            case 1: launch_cfg<MODE, EPI, 2, 1, 1, 4, KC>(p, grid, lds, s); return true;
-            case 2: launch_cfg<MODE, EPI, 1, 2, 1, 4, KC>(p, grid, lds, s); return true;
-            case 3: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
-            case 4: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
-        }
-    } else {
-        switch (cfg) {
-            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 2, KC>(p, grid, lds, s); return true;
-            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 4, KC>(p, grid, lds, s); return true;
-            case 2: launch_cfg<MODE, EPI, 1, 8, 1, 4, KC>(p, grid, lds, s); return true;
-            case 3: launch_cfg<MODE, EPI, 1, 2, 2, 2, KC>(p, grid, lds, s); return true;
-            case 4: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
-            case 5: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
-        }
+    switch (cfg) {
+        case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC>(p, grid, lds, s); return true;
+        case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC>(p, grid, lds, s); return true;
+        case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC>(p, grid, lds, s); return true;
+        case 3: launch_cfg<MODE, EPI, 2, 2, 2, 2, KC>(p, grid, lds, s); return true;
+        case 4: launch_cfg<MODE, EPI, 1, 4, 2, 2, KC>(p, grid, lds, s); return true;
+        case 5: launch_cfg<MODE, EPI, 1, 2, 2, 2, KC>(p, grid, lds, s); return true;
+        case 6: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
+        case 7: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
     }
     return false;
 }
 
-static const TileCfg kCfgStd[] = {{2, 4, 2, 2}, {2, 4, 1, 4}, {1, 8, 1, 4}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}};
-static const TileCfg kCfgUp[] = {{2, 1, 2, 2}, {2, 1, 1, 4}, {1, 2, 1, 4}, {1, 1, 2, 2}, {1, 1, 4, 1}};
+static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},               // 512 threads, 1 workgroup / CU
+                                   {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}};  // 256 threads
+static const int kNumCfg = 8;
 
 static int next_pow2(int v) {
     int r = 1;
@@ -359,11 +455,13 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     else if (mode == W2E_CONV_UP) p.in_h = h, p.in_w = w, p.out_h = 2 * h + 1, p.out_w = 2 * w + 1;
     else p.in_h = 2 * h + 1, p.in_w = 2 * w + 1, p.out_h = h, p.out_w = w;
 
-    // ---- pick the tile configuration with a small cost model: a "round" is one workgroup per CU; a
-    // workgroup's time is its per-wave MFMA chain (64 cycles per 32x32x2) plus part of its staging.
+    // ---- pick the tile configuration with a small cost model.  Unit = MFMA cycles on one SIMD.  A CU works
+    // through ceil(wgs/256) workgroups (two resident 256-thread workgroups share its matrix pipes, so they
+    // do not go faster than one after the other); a workgroup's time is its per-SIMD MFMA chain plus the
+    // part of its staging (barriers, LDS writes) that the register prefetch cannot hide.
     const bool up = mode == W2E_CONV_UP;
-    const TileCfg* cfgs = up ? kCfgUp : kCfgStd;
-    const int ncfg = up ? 5 : 6;
+    const TileCfg* cfgs = kCfgStd;
+    const int ncfg = kNumCfg;
     const int kc = mode == W2E_CONV_DOWN ? 4 : 8;
     const int wp2 = next_pow2(w);
     int best = -1;
@@ -376,12 +474,20 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const int ph = mode == W2E_CONV_SAME ? th + 2 : (up ? th + 1 : 2 * th + 1);
         const int pw = mode == W2E_CONV_SAME ? tw + 2 : (up ? tw + 1 : 2 * tw + 1);
         if (sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw) > 64 * 1024) continue;
-        const double wgs = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
-        const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;
-        const double t_mfma = (double)cfgs[c].nob * cfgs[c].npb * (up ? 4.0 : 1.0) * (k_ch / 2.0) * (up ? 2.25 : 9.0) * 64.0;
-        const double t_stage = (double)ceil_div(k_ch, kc) * 2500.0;
-        const double cost = rounds * (t_mfma + 0.5 * t_stage) + (wgs <= 256.0 ? 0.5 * t_stage : 0.0);
-        if (best < 0 || cost < best_cost * 0.98) best = c, best_cost = cost;
+        const int nt = 64 * cfgs[c].wo * cfgs[c].wp;
+        if (ph * pw > nt * max_patch_slots(mode, tm, nt)) continue;  // register-prefetch slots per thread
+        const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
+        const double waves_per_simd = nt / 256.0;
+        const double unit = (double)cfgs[c].nob * cfgs[c].npb * waves_per_simd * (k_ch / 2.0) * 64.0;  // one tap
+        const double t_stage = (double)ceil_div(k_ch, kc) * 1200.0;
+        double cost;
+        if (up) {  // 4 phases with 4/2/2/1 taps, heaviest dispatched first
+            const double per_cu = ceil(4.0 * tiles / 256.0) / 4.0;  // tiles (sets of 4 phases) per CU
+            cost = per_cu * (9.0 * unit + 4.0 * t_stage) + (4.0 * tiles < 1024.0 ? 1.75 * unit : 0.0);
+        } else {
+            cost = ceil(tiles / 256.0) * (9.0 * unit + t_stage);
+        }
+        if (best < 0 || cost < best_cost * 0.97) best = c, best_cost = cost;
     }
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
@@ -399,7 +505,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
     const size_t lds = sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     W2E_REQUIRE(lds <= 64 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
-    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch;
+    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * (up ? 4 : 1);
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
     bool ok = false;
@@ -416,8 +522,14 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
     W2E_LAUNCH_CHECK("modconv3x3");
     if (up) {
-        const int64_t total = (int64_t)batch * (2 * w + 1 + 2 * h) * n_ch;
-        upconv_border_kernel<<<stream_grid(total, 256), 256, 0, s>>>(p);
+        const int groups_row = (int)ceil_div(2 * w + 1, 8), groups_col = (int)ceil_div(2 * h, 8);
+        if (n_ch >= 64) {
+            dim3 grid((unsigned)(batch * (groups_row + groups_col)), (unsigned)ceil_div(n_ch, 64));
+            upconv_border_kernel<64><<<grid, 256, 0, s>>>(p, groups_row, groups_col);
+        } else {
+            dim3 grid((unsigned)(batch * (groups_row + groups_col)), (unsigned)ceil_div(n_ch, 32));
+            upconv_border_kernel<32><<<grid, 256, 0, s>>>(p, groups_row, groups_col);
+        }
         W2E_LAUNCH_CHECK("modconv3x3 border");
     }
     return 0;

@@ -35,13 +35,18 @@ __device__ __forceinline__ float epilogue(const UpfirdnParams& p, float v, int64
     return (v > 0.f ? v : v * p.slope) * p.gain;
 }
 
-constexpr int TW = 64, TH = 16;
+constexpr int TW = 64, TH = 32;  // output tile of a 256-thread block; each thread: 4 wide x 2 tall
+constexpr int MAX_TILE_K = 8;    // taps per axis the tile kernel handles (pitch / LDS sized for it)
 
-__global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y) {
+// up = down = 1.  The (TH+kh-1) x (TW+kw-1) input tile is staged once into LDS (row pitch a multiple of 4
+// floats so each thread's window rows are 16-B aligned: ds_read_b128), every thread then slides the taps
+// over a register window: 2*(kw+3) LDS floats read per 8 outputs.
+__global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* kbuf = smem;            // kh*kw taps, already oriented for correlation
+    float* kbuf = smem;  // kh*kw taps, already oriented for correlation
     float* tile = smem + MAXK * MAXK;
     const int pw = TW + p.kw - 1, ph = TH + p.kh - 1;
+    const int pitch = (pw + 3) & ~3;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.kh * p.kw; i += 256) {
         const int ky = i / p.kw, kx = i % p.kw;
@@ -49,6 +54,7 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int 
     }
     const float nw = (p.act && p.noise) ? p.noise_w[0] : 0.f;
     const int64_t n_tiles = (int64_t)tiles_x * tiles_y * p.planes;
+    const int ly = (tid >> 4) * 2, lx = (tid & 15) * 4;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int tx = (int)(t % tiles_x);
         const int ty = (int)((t / tiles_x) % tiles_y);
@@ -58,32 +64,53 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int 
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
         __syncthreads();  // previous iteration's readers are done (also orders the kbuf fill)
         for (int i = tid; i < ph * pw; i += 256) {
-            const int r = i / pw, c = i - r * pw;
+            const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * pw;
             const int iy = iy0 + r, ix = ix0 + c;
-            tile[i] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? src[(int64_t)iy * p.in_w + ix] : 0.f;
+            tile[r * pitch + c] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? src[(int64_t)iy * p.in_w + ix] : 0.f;
         }
         __syncthreads();
-        const int ly = tid >> 4, lx = (tid & 15) << 2;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ky = 0; ky < p.kh; ++ky) {
-            const float* row = tile + (ly + ky) * pw + lx;
-            for (int kx = 0; kx < p.kw; ++kx) {
-                const float k = kbuf[ky * p.kw + kx];
+        float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int r = 0; r < p.kh + 1; ++r) {  // input rows ly+r feed output row 0 with ky=r and row 1 with ky=r-1
+            float win[4 + MAX_TILE_K - 1 + 1];
+            const float4* rp = reinterpret_cast<const float4*>(tile + (ly + r) * pitch + lx);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += k * row[kx + j];
+            for (int q = 0; q < (4 + MAX_TILE_K - 1 + 3) / 4; ++q) {
+                if (q * 4 < 4 + p.kw - 1) {
+                    const float4 v = rp[q];
+                    win[q * 4] = v.x, win[q * 4 + 1] = v.y, win[q * 4 + 2] = v.z, win[q * 4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int kx = 0; kx < MAX_TILE_K; ++kx) {
+                if (kx < p.kw) {
+                    if (r < p.kh) {
+                        const float k0 = kbuf[r * p.kw + kx];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[0][j] += k0 * win[kx + j];
+                    }
+                    if (r >= 1) {
+                        const float k1 = kbuf[(r - 1) * p.kw + kx];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[1][j] += k1 * win[kx + j];
+                    }
+                }
             }
         }
-        const int oy = oy0 + ly, ox = ox0 + lx;
-        if (oy < p.out_h && ox < p.out_w) {
-            float* dst = p.y + (plane * p.out_h + oy) * (int64_t)p.out_w + ox;
+        const int ox = ox0 + lx;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = epilogue(p, acc[j], plane, oy, ox + j < p.out_w ? ox + j : ox, nw);
+        for (int yy = 0; yy < 2; ++yy) {
+            const int oy = oy0 + ly + yy;
+            if (oy >= p.out_h || ox >= p.out_w) continue;
+            float* dst = p.y + (plane * p.out_h + oy) * (int64_t)p.out_w + ox;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = epilogue(p, acc[yy][j], plane, oy, ox + j < p.out_w ? ox + j : ox, nw);
             if (ox + 3 < p.out_w && (p.out_w & 3) == 0) {
-                *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (ox + j < p.out_w) dst[j] = acc[j];
+                    if (ox + j < p.out_w) dst[j] = v[j];
             }
         }
     }
@@ -140,12 +167,14 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip,
                     act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain};
     hipStream_t s = (hipStream_t)stream;
-    if (up == 1 && down == 1 && out_w >= 16) {
+    if (up == 1 && down == 1 && out_w >= 32 && kh <= MAX_TILE_K && kw <= MAX_TILE_K) {
         const int tiles_x = (int)ceil_div(out_w, TW), tiles_y = (int)ceil_div(out_h, TH);
         const int64_t n_tiles = planes * tiles_x * tiles_y;
-        const size_t lds = sizeof(float) * (MAXK * MAXK + (size_t)(TH + kh - 1) * (TW + kw - 1));
-        const int grid = (int)(n_tiles < 8192 ? n_tiles : 8192);
-        upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y);
+        const int pw = TW + kw - 1, pitch = (pw + 3) & ~3;
+        const size_t lds = sizeof(float) * (MAXK * MAXK + (size_t)(TH + kh) * pitch + 16);
+        const int grid = (int)(n_tiles < 16384 ? n_tiles : 16384);
+        const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)pw + 1);
+        upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
     } else {
         upfirdn_generic_kernel<<<stream_grid(total, 256), 256, 0, s>>>(p, total);
     }

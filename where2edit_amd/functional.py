@@ -9,7 +9,7 @@ import math
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _lib, profiling
 from ._lib import call, ptr, stream_ptr
 
 SQRT2 = math.sqrt(2.0)
@@ -30,8 +30,11 @@ def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=
     else:
         out_scale, noise, noise_w, bias = act
         a = (1, ptr(out_scale), ptr(noise), ptr(noise_w), ptr(bias), c, 0.2, SQRT2)
+    sp = profiling.span("upfirdn2d", 4.0 * n * c * (h * w + out_h * out_w))  # algorithmic bytes: read x + write y
     call("w2e_upfirdn2d", ptr(x), ptr(kernel), ptr(y), n * c, h, w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0,
          int(flip), *a, stream_ptr())
+    if sp is not None:
+        sp.end()
     return y
 
 
@@ -135,8 +138,12 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     noise = noise_w = bias = None
     if act is not None:
         noise, noise_w, bias = act
+    # algorithmic FLOPs: 2*K*N*9 per domain pixel (MACs actually needed; SURVEY 2.3 convention)
+    sp = profiling.span("modconv3x3", 2.0 * b * k * n * 9 * h * w)
     call("w2e_modconv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n, h, w,
          int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
+    if sp is not None:
+        sp.end()
     return y, dot
 
 
