@@ -3,7 +3,13 @@ import ctypes
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
-PROTOS = {}
+PROTOS = {
+    "w2e_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "w2e_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "w2e_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "w2e_attn_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "w2e_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+}
 
 
 def declare(lib):
