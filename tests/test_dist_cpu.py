@@ -1,0 +1,104 @@
+"""Data-parallel host logic on CPU: world_size-2 gloo processes.  (The kernels need a GPU; what is covered
+here is everything between backward and optimizer.step: sharding, the flat gradient bucket, the mean
+all-reduce, and that replicas stay bit-identical under Ranger.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import seeded
+from helpers import assert_close, golden
+from make_golden import RANGER_SHAPES
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _toy():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from where2edit_amd import dist as wd
+    from where2edit_amd.ranger import Ranger
+    r, w, _ = wd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    net = _toy()
+    bucket = wd.GradBucket(net.parameters())
+    opt = Ranger(net.parameters(), lr=0.05)
+    data = seeded.tensor("dist.x", (8, 16))
+    target = seeded.tensor("dist.y", (8, 8))
+    for step in range(7):  # crosses the k=6 lookahead sync
+        bucket.zero()
+        xs, ys = wd.shard(data, rank, world), wd.shard(target, rank, world)
+        loss = ((net(xs) - ys) ** 2).mean()  # per-sample mean over an equal shard
+        loss.backward()
+        if step == 0:
+            local = bucket.flat.clone()
+        bucket.all_reduce_mean()
+        if step == 0:
+            reduced = bucket.flat.clone()
+        opt.step()
+    torch.save({"local": local, "reduced": reduced, "params": [p.detach().clone() for p in net.parameters()],
+                "views": all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net.parameters())},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_full_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    # full-batch reference in this process
+    net = _toy()
+    data, target = seeded.tensor("dist.x", (8, 16)), seeded.tensor("dist.y", (8, 8))
+    ((net(data) - target) ** 2).mean().backward()
+    full = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert res[0]["views"] and res[1]["views"]
+    assert not torch.allclose(res[0]["local"], res[1]["local"])          # shards differ before the collective
+    assert torch.equal(res[0]["reduced"], res[1]["reduced"])              # identical after it
+    assert_close(res[0]["reduced"], full, 1e-6, "mean of shard grads == full-batch grad")
+    for a, b in zip(res[0]["params"], res[1]["params"]):
+        assert torch.equal(a, b)                                          # replicas stay bit-identical
+
+
+def test_shard_and_env_defaults(monkeypatch):
+    from where2edit_amd import dist as wd
+    x = torch.arange(24).view(8, 3)
+    assert torch.equal(wd.shard(x, 1, 4), x[2:4])
+    with pytest.raises(ValueError):
+        wd.shard(x, 0, 3)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert wd.init_from_env() == (0, 1, 0)
+    b = wd.GradBucket(_toy().parameters())
+    assert b.nbytes == 4 * (16 * 32 + 32 + 32 * 8 + 8)
+    b.all_reduce_mean()  # no process group: a no-op
+
+
+def test_ranger_matches_reference_fixture():
+    """where2edit_amd.ranger.Ranger against mapper/training/ranger.py outputs (13 steps, lr 0.5)."""
+    from where2edit_amd.ranger import Ranger
+    g = golden("ranger")
+    params = [torch.nn.Parameter(seeded.tensor("ranger.p." + n, s)) for n, s in RANGER_SHAPES]
+    opt = Ranger(params, lr=0.5)
+    for it in range(13):
+        for (n, s), p in zip(RANGER_SHAPES, params):
+            p.grad = seeded.tensor(f"ranger.g.{n}", s, salt=it)
+        opt.step()
+        for (n, _), p in zip(RANGER_SHAPES, params):
+            assert_close(p, g[f"step{it}.{n}"], 1e-5, f"step {it} {n}")
+    st = opt.state[params[0]]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq", "slow_buffer"} and st["step"] == 13
+    with pytest.raises(ValueError):
+        Ranger(params, lr=0.0)

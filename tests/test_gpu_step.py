@@ -1,0 +1,128 @@
+"""The unit of the headline metric: one mapper training step (mapper/training/coach.py:79-92) on the HIP
+path against the CPU oracle's step, and the 2-rank data-parallel step against the single-process one."""
+import os
+import socket
+import types
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import seeded
+from helpers import assert_close, assert_grad_close, golden
+from make_golden import CLIP_TINY
+from oracle import step as OS
+from oracle import stylegan2 as OG
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SIZE = 64
+
+
+def _opts(**kw):
+    base = dict(mapper_type="LevelsMapper", no_coarse_mapper=False, no_medium_mapper=False, no_fine_mapper=False,
+                work_in_stylespace=False, stylegan_size=SIZE, checkpoint_path=None, stylegan_weights=None, batch_size=2,
+                test_batch_size=1, learning_rate=0.5, optim_name="ranger", id_lambda=0.0, clip_lambda=1.0,
+                latent_l2_lambda=0.8, max_steps=2)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def _coach(opts, data_parallel=False, device=DEV):
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.coach import Coach
+    from where2edit_amd.styleclip_mapper import StyleCLIPMapper
+    net = StyleCLIPMapper(opts)
+    net.decoder.load_state_dict(seeded.generator_state_dict(SIZE), strict=True)
+    msd = seeded.mapper_state_dict(["course_mapping.", "medium_mapping.", "fine_mapping."])
+    net.mapper.load_state_dict(msd, strict=True)
+    c = CLIP_TINY
+    clip = CLIP(embed_dim=c["embed_dim"], vision_layers=c["vision_layers"], vision_width=c["vision_width"],
+                context_length=c["context_length"], vocab_size=c["vocab_size"], transformer_width=c["text_width"],
+                transformer_heads=1, transformer_layers=c["text_layers"])
+    clip.load_state_dict(seeded.clip_state_dict(**c), strict=True)
+    tokens = torch.from_numpy(golden("clip_hf")["tiny.tokens"])[:1]
+    return Coach(opts, net=net, clip_loss=CLIPLoss(opts, model=clip), text_inputs=tokens, device=device,
+                 data_parallel=data_parallel), msd, tokens
+
+
+def test_train_step_matches_oracle_step():
+    coach, msd, tokens = _coach(_opts())
+    w = seeded.wplus_latents(2, OG.n_latent(SIZE), salt=21)
+    # oracle: same weights, CPU
+    gsd, csd = seeded.generator_state_dict(SIZE), seeded.clip_state_dict(**CLIP_TINY)
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    loss_o, terms, x_o, xh_o, wh_o = OS.mapper_step_loss(gsd, osd, csd, w, tokens, size=SIZE, clip_lambda=1.0, latent_l2_lambda=0.8)
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    # HIP: forward pieces, then a full train_step
+    x, x_hat, w_hat = coach.forward_pair(w.to(DEV))
+    assert_close(x, x_o, 1e-4, "x = G(w)"), assert_close(x_hat, xh_o, 1e-4, "x_hat"), assert_close(w_hat, wh_o, 1e-5, "w_hat")
+    before = {n: p.detach().clone() for n, p in coach.net.mapper.named_parameters()}
+    d = coach.train_step(w.to(DEV))
+    assert abs(float(d["loss"]) - loss_o.item()) <= 1e-4 * abs(loss_o.item())
+    assert abs(float(d["loss_clip"]) - terms["loss_clip"].item()) <= 1e-4 * abs(terms["loss_clip"].item())
+    assert abs(float(d["loss_l2_latent"]) - terms["loss_l2_latent"].item()) <= 1e-4 * abs(terms["loss_l2_latent"].item())
+    params = dict(coach.net.mapper.named_parameters())
+    flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
+    flat_o = torch.cat([g.reshape(-1) for g in grads_o])
+    assert_grad_close(flat_h, flat_o, "mapper gradients")
+    # the optimizer moved the mapper exactly as the oracle's Ranger does when fed the HIP gradients
+    st = OS.RangerState([before[n].cpu() for n in names], lr=0.5)
+    ps = [before[n].cpu().clone() for n in names]
+    st.step(ps, [params[n].grad.cpu() for n in names])
+    for n, p in zip(names, ps):
+        assert_close(params[n].detach(), p, 1e-5, f"post-step {n}")
+    # only the mapper is optimised (coach.py:174-180); the frozen 3x3 conv weights get no weight-gradient pass at all
+    assert all(p.grad is None for p in coach.net.decoder.parameters() if p.ndim == 5 and p.shape[-1] == 3)
+    assert coach.global_step == 1
+
+
+def test_adam_and_validate_and_checkpoint(tmp_path):
+    coach, _, _ = _coach(_opts(optim_name="adam", learning_rate=0.01))
+    lat = seeded.wplus_latents(4, OG.n_latent(SIZE), salt=5)
+    log = coach.train(lat, max_steps=2, generator=torch.Generator().manual_seed(0))
+    assert len(log) == 2 and all(torch.isfinite(d["loss"]) for d in log)
+    v = coach.validate(lat[:2])
+    assert set(v) >= {"loss", "loss_clip", "loss_l2_latent"}
+    path = tmp_path / "ckpt" / "iteration_2.pt"
+    coach.checkpoint_me(str(path))
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"state_dict", "opts"} and any(k.startswith("mapper.course_mapping") for k in ck["state_dict"])
+    assert any(k.startswith("decoder.convs.0.conv.weight") for k in ck["state_dict"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(here, "golden"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from where2edit_amd import dist as wd
+    wd.init_from_env(backend="gloo")  # both ranks share the one GPU of this box; RCCL wants one device per rank
+    coach, _, _ = _coach(_opts(), data_parallel=True)
+    w = seeded.wplus_latents(4, OG.n_latent(SIZE), salt=33)
+    coach.train_step(wd.shard(w, rank, world).to(DEV))
+    torch.save({n: p.detach().cpu() for n, p in coach.net.mapper.named_parameters()}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_full_batch_step(tmp_path):
+    world = 2
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    coach, _, _ = _coach(_opts(batch_size=4))
+    coach.train_step(seeded.wplus_latents(4, OG.n_latent(SIZE), salt=33).to(DEV))
+    for n, p in coach.net.mapper.named_parameters():
+        assert torch.equal(a[n], b[n]), n                       # replicas identical after the all-reduce
+        assert_close(a[n], p.detach(), 2e-4, f"dp2 == single-process full batch: {n}")
