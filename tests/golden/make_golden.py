@@ -458,19 +458,7 @@ def case_irse():
     _import_reference()
     from models.facial_recognition.model_irse import Backbone
     net = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se").eval()
-    sd = {}
-    for k, v in net.state_dict().items():
-        if k.endswith("num_batches_tracked"):
-            sd[k] = v
-        elif k.endswith("running_var"):
-            sd[k] = seeded.tensor("irse." + k, v.shape, 0.1, 1.0).abs() + 0.5
-        elif k.endswith("running_mean"):
-            sd[k] = seeded.tensor("irse." + k, v.shape, 0.1)
-        elif v.ndim == 1:  # BN weight/bias, PReLU slope
-            sd[k] = seeded.tensor("irse." + k, v.shape, 0.05, 0.25 if "PReLU" in k else (1.0 if k.endswith("weight") else 0.0))
-        else:
-            fan_in = v[0].numel()
-            sd[k] = seeded.tensor("irse." + k, v.shape, fan_in ** -0.5)
+    sd = seeded.irse_fill(net.state_dict())
     net.load_state_dict(sd, strict=True)
     x = seeded.tensor("irse.x", (2, 3, 112, 112), 0.5)
     with torch.no_grad():

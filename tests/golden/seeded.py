@@ -140,3 +140,21 @@ def wplus_latents(batch, n_latent, salt=0):
 def sample_positions(numel, count, key):
     g = torch.Generator().manual_seed(zlib.crc32(key.encode()) % (2 ** 31))
     return torch.randint(0, numel, (count,), generator=g)
+
+
+def irse_fill(state_dict, salt=0):
+    """Deterministic IR-SE50 weights keyed by the reference's state_dict names (used by make_golden.case_irse and
+    the tests): BN statistics near (0,1), 1-D affine/PReLU weights near 1, biases near 0, conv/linear ~ fan_in^-0.5."""
+    sd = {}
+    for k, v in state_dict.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = v.clone()
+        elif k.endswith("running_var"):
+            sd[k] = tensor("irse." + k, v.shape, 0.1, 1.0, salt).abs() + 0.5
+        elif k.endswith("running_mean"):
+            sd[k] = tensor("irse." + k, v.shape, 0.1, 0.0, salt)
+        elif v.ndim == 1:
+            sd[k] = tensor("irse." + k, v.shape, 0.05, 1.0 if k.endswith("weight") else 0.0, salt)
+        else:
+            sd[k] = tensor("irse." + k, v.shape, v[0].numel() ** -0.5, 0.0, salt)
+    return sd

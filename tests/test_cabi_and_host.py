@@ -130,3 +130,22 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no fallback"):
         _lib.load()
+
+
+def test_irse50_backbone_matches_reference_fixture():
+    """A9: the IR-SE50 ArcFace backbone (stock torch ops) reproduces the reference's Backbone on seeded weights,
+    with the reference's state_dict keys.  Runs on CPU: it is not a hand-kernel target."""
+    from helpers import assert_close, golden
+    from where2edit_amd.id_loss import Backbone, IDLoss
+    g = golden("irse")
+    net = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se").eval()
+    assert sorted(net.state_dict()) == [str(k) for k in g["keys"]]
+    net.load_state_dict(seeded.irse_fill(net.state_dict()), strict=True)
+    with torch.no_grad():
+        y = net(seeded.tensor("irse.x", (2, 3, 112, 112), 0.5))
+    assert_close(y, g["feats"], 1e-4)
+    loss_mod = IDLoss(types.SimpleNamespace(ir_se50_weights=None))
+    a = seeded.tensor("irse.a", (1, 3, 256, 256), 0.5)
+    with torch.no_grad():
+        l_same, zero = loss_mod(a, a)
+    assert abs(float(l_same)) < 1e-5 and zero == 0

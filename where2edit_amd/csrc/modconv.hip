@@ -50,6 +50,7 @@ struct ConvParams {
     int tiles_x, tiles_y, tiles_n;
     int ph, pw, plane;
     unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
+    int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
 };
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
@@ -60,28 +61,43 @@ __host__ __device__ constexpr int max_patch_slots(int mode, int tm, int nt) {
                                  : (nt == 512 ? (tm >= 2048 ? 5 : (tm >= 1024 ? 3 : 2)) : (tm >= 256 ? 2 : 1));
 }
 
-__device__ __forceinline__ bool tap_in_phase(int tap, int phase) {
-    return ((tap / 3) & 1) == (phase >> 1) && ((tap % 3) & 1) == (phase & 1);
-}
+// Tap bookkeeping.  SAME/DOWN use all 9 taps.  An UP workgroup owns ONE output phase (PY,PX) and only its taps
+// exist: ta in {0,2} if PY==0 else {1}; tb likewise -> 4/2/2/1 taps, stored compactly (slot = ia*NB + ib).
+template <int MODE, int PY, int PX>
+struct Taps {
+    static constexpr int NA = (MODE == W2E_CONV_UP) ? (PY ? 1 : 2) : 3;
+    static constexpr int NB = (MODE == W2E_CONV_UP) ? (PX ? 1 : 2) : 3;
+    static constexpr int N = NA * NB;
+    __host__ __device__ static constexpr int ta(int slot) { return (MODE == W2E_CONV_UP) ? (PY ? 1 : 2 * (slot / NB)) : slot / 3; }
+    __host__ __device__ static constexpr int tb(int slot) { return (MODE == W2E_CONV_UP) ? (PX ? 1 : 2 * (slot % NB)) : slot % 3; }
+};
 
-// One K-chunk of MFMAs for a wave: channel pairs x taps.  For UP, (PY,PX) is the output phase and only
-// taps with (ta&1)==PY, (tb&1)==PX exist (resolved at compile time after unrolling).
-template <int MODE, int NOB, int NPB, int KC, int TN, int PY, int PX>
+// Channels per K-chunk: the light UP phases take deeper chunks so that every chunk carries a comparable number
+// of MFMAs between its two barriers (phase 0: 8 ch x 4 taps; phases 1,2: 16 x 2; phase 3: 16 x 1).
+template <int MODE, int KC, int PY, int PX, int NACC, int MAXX>
+struct Chunk {
+    static constexpr int NT_ = Taps<MODE, PY, PX>::N;
+    // (8-accumulator tiles and tiles with > 2 patch slots per thread keep KC: their register budget has no room
+    // for a deeper prefetch)
+    static constexpr int KCP = (MODE == W2E_CONV_UP && NACC < 8 && MAXX <= 2) ? ((KC * 4 / NT_) > 16 ? 16 : (KC * 4 / NT_)) : KC;
+};
+
+// One K-chunk of MFMAs for a wave: channel pairs x taps.
+template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float* ws, const float* xs, int a_base,
                                            const int (&base)[NPB], int pw, int plane) {
-    constexpr int NTAPS = (MODE == W2E_CONV_UP) ? (PY ? 1 : 2) * (PX ? 1 : 2) : 9;
+    using T = Taps<MODE, PY, PX>;
     // big register tiles keep the pair loop rolled: >= 32 MFMAs per iteration already hide the LDS latency
-    constexpr int WORK = NOB * NPB * NTAPS;
-    constexpr int UNR = WORK >= 32 ? 1 : (WORK >= 16 ? 2 : KC / 2);
+    constexpr int WORK = NOB * NPB * T::N;
+    constexpr int UNR = WORK >= 32 ? 1 : (WORK >= 16 ? 2 : (KCP / 2 > 4 ? 4 : KCP / 2));
 #pragma unroll UNR
-    for (int c2 = 0; c2 < KC / 2; ++c2) {
+    for (int c2 = 0; c2 < KCP / 2; ++c2) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ta = tap / 3, tb = tap % 3;
-            if (MODE == W2E_CONV_UP && (((ta & 1) != PY) || ((tb & 1) != PX))) continue;
+        for (int slot = 0; slot < T::N; ++slot) {
+            const int ta = T::ta(slot), tb = T::tb(slot);
             float av[NOB], bv[NPB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (c2 * 18 + tap) * TN + ob * 32];
+            for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (c2 * 2 * T::N + slot) * TN + ob * 32];
             int toff;
             if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * pw - (tb >> 1);
             else toff = ta * pw + tb;
@@ -102,8 +118,9 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     constexpr int TN = 32 * NOB * WO;
     constexpr int MAXX = max_patch_slots(MODE, 32 * NPB * WP, NT);  // activation-patch elements per thread (x KC channels)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ws = smem;                 // [KC*9][TN]
-    float* xs = smem + KC * 9 * TN;   // [KC][plane]
+    constexpr int WS_FLOATS = (MODE == W2E_CONV_UP ? 32 : KC * 9) * TN;  // every phase stages KCP*NTAPS = 32 rows
+    float* ws = smem;              // [KCP][NTAPS][TN]
+    float* xs = smem + WS_FLOATS;  // [KCP][plane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -114,6 +131,10 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int per_phase = gridDim.x >> 2;
     const int phase = (MODE == W2E_CONV_UP) ? bid / per_phase : 0;
     if (MODE == W2E_CONV_UP) bid -= phase * per_phase;
+    const int ks = bid % p.splits;
+    bid /= p.splits;
+    const int k_lo = ks * p.k_per;
+    const int k_hi = (k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -138,7 +159,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         if (!ok) off = (MODE == W2E_CONV_UP) ? p.pw + 1 : 0;
         base[pb] = half * p.plane + off;
     }
-    const int a_base = half * 9 * TN + wo * NOB * 32 + j;
 
     f32x16 acc[NOB][NPB];
 #pragma unroll
@@ -157,77 +177,80 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     // ---- software pipeline (T14 "issue early / write late"): the global loads of chunk k+1 are issued into
     // registers right after chunk k is published to LDS and land while chunk k's MFMAs run; they are
     // written to LDS (activations multiplied by in_scale on the way) after the barrier that retires chunk k.
-    constexpr int WQ = (KC * 9 * TN / 4 + NT - 1) / NT;  // float4 weight slots per thread
-    float4 wr[WQ];
-    float xr[MAXX][KC];
-    float sc[KC];
-
-    auto prefetch = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < WQ; ++t) {
-            const int q = tid + t * NT;
-            const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
-            const int kr = k0 * 9 + r, n = n0 + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool want = q < KC * 9 * TN / 4 && kr < p.K * 9 && (MODE != W2E_CONV_UP || tap_in_phase(r % 9, phase));
-            if (want) {
-                const float* wsrc = p.wp + (int64_t)kr * p.N + n;
-                if (wvec) {
-                    if (n < p.N) v = *reinterpret_cast<const float4*>(wsrc);
-                } else {
-                    if (n < p.N) v.x = wsrc[0];
-                    if (n + 1 < p.N) v.y = wsrc[1];
-                    if (n + 2 < p.N) v.z = wsrc[2];
-                    if (n + 3 < p.N) v.w = wsrc[3];
-                }
-            }
-            wr[t] = v;
-        }
-#pragma unroll
-        for (int ci = 0; ci < KC; ++ci)
-            sc[ci] = (k0 + ci < p.K) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + k0 + ci] : 1.f) : 0.f;
-        const float* xb = p.x + ((int64_t)b * p.K + k0) * in_plane;
-#pragma unroll
-        for (int t = 0; t < MAXX; ++t) {
-            const int idx = tid + t * NT;
-            const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
-            const int px = idx - py * p.pw;
-            const int iy = oy0 + py, ix = ox0 + px;
-            const bool inb = idx < patch && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-            const float* src = xb + (int64_t)iy * p.in_w + ix;
-#pragma unroll
-            for (int ci = 0; ci < KC; ++ci) xr[t][ci] = (inb && k0 + ci < p.K) ? src[ci * in_plane] : 0.f;
-        }
-    };
-    auto commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < WQ; ++t) {
-            const int q = tid + t * NT;
-            const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
-            if (q < KC * 9 * TN / 4 && (MODE != W2E_CONV_UP || tap_in_phase(r % 9, phase)))
-                *reinterpret_cast<float4*>(ws + r * TN + c4) = wr[t];
-        }
-#pragma unroll
-        for (int t = 0; t < MAXX; ++t) {
-            const int idx = tid + t * NT;
-            if (idx < patch) {
-#pragma unroll
-                for (int ci = 0; ci < KC; ++ci) xs[ci * p.plane + idx] = xr[t][ci] * sc[ci];
-            }
-        }
-    };
-
-    // The K loop, instantiated once per output phase for UP (the phase is uniform per workgroup; keeping the
-    // switch OUTSIDE the loop gives each phase its own loop nest and register allocation).
+    // Instantiated once per output phase for UP (the phase is uniform per workgroup; the switch sits OUTSIDE
+    // the loop so that each phase gets its own loop nest and register allocation).
     auto k_loop = [&](auto py_c, auto px_c) __attribute__((always_inline)) {
         constexpr int PY = decltype(py_c)::value, PX = decltype(px_c)::value;
-        prefetch(0);
-        for (int k0 = 0; k0 < p.K; k0 += KC) {
+        using T = Taps<MODE, PY, PX>;
+        constexpr int KCP = Chunk<MODE, KC, PY, PX, NOB * NPB, MAXX>::KCP;
+        constexpr int WROWS = KCP * T::N;                      // rows of the staged weight chunk
+        constexpr int WQ = (WROWS * TN / 4 + NT - 1) / NT;     // float4 weight slots per thread
+        const int a_base = half * T::N * TN + wo * NOB * 32 + j;
+        float4 wr[WQ];
+        float xr[MAXX][KCP];
+        float sc[KCP];
+
+        auto prefetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < WQ; ++t) {
+                const int q = tid + t * NT;
+                const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
+                const int ci = r / T::N, slot = r % T::N;
+                const int tap = T::ta(slot) * 3 + T::tb(slot);
+                const int n = n0 + c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < WROWS * TN / 4 && k0 + ci < k_hi) {
+                    const float* wsrc = p.wp + ((int64_t)(k0 + ci) * 9 + tap) * p.N + n;
+                    if (wvec) {
+                        if (n < p.N) v = *reinterpret_cast<const float4*>(wsrc);
+                    } else {
+                        if (n < p.N) v.x = wsrc[0];
+                        if (n + 1 < p.N) v.y = wsrc[1];
+                        if (n + 2 < p.N) v.z = wsrc[2];
+                        if (n + 3 < p.N) v.w = wsrc[3];
+                    }
+                }
+                wr[t] = v;
+            }
+#pragma unroll
+            for (int ci = 0; ci < KCP; ++ci)
+                sc[ci] = (k0 + ci < k_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + k0 + ci] : 1.f) : 0.f;
+            const float* xb = p.x + ((int64_t)b * p.K + k0) * in_plane;
+#pragma unroll
+            for (int t = 0; t < MAXX; ++t) {
+                const int idx = tid + t * NT;
+                const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
+                const int px = idx - py * p.pw;
+                const int iy = oy0 + py, ix = ox0 + px;
+                const bool inb = idx < patch && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+                const float* src = xb + (int64_t)iy * p.in_w + ix;
+#pragma unroll
+                for (int ci = 0; ci < KCP; ++ci) xr[t][ci] = (inb && k0 + ci < k_hi) ? src[ci * in_plane] : 0.f;
+            }
+        };
+        auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < WQ; ++t) {
+                const int q = tid + t * NT;
+                if (q < WROWS * TN / 4) *reinterpret_cast<float4*>(ws + q * 4) = wr[t];
+            }
+#pragma unroll
+            for (int t = 0; t < MAXX; ++t) {
+                const int idx = tid + t * NT;
+                if (idx < patch) {
+#pragma unroll
+                    for (int ci = 0; ci < KCP; ++ci) xs[ci * p.plane + idx] = xr[t][ci] * sc[ci];
+                }
+            }
+        };
+
+        prefetch(k_lo);
+        for (int k0 = k_lo; k0 < k_hi; k0 += KCP) {
             __syncthreads();  // everyone finished reading the previous chunk
             commit();
             __syncthreads();
-            if (k0 + KC < p.K) prefetch(k0 + KC);
-            mfma_chunk<MODE, NOB, NPB, KC, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane);
+            if (k0 + KCP < k_hi) prefetch(k0 + KCP);
+            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane);
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -289,7 +312,8 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                         v += bs + (p.noise ? nw * p.noise[(int64_t)gy[pb] * p.out_w + gx[pb]] : 0.f);
                         v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
                     }
-                    p.y[oi] = v;
+                    if (p.splits > 1) atomicAdd(&p.y[oi], v);
+                    else p.y[oi] = v;
                 }
             }
             if (EPI == EPI_DOT) {
@@ -330,24 +354,40 @@ __global__ __launch_bounds__(256) void upconv_border_kernel(ConvParams p, int gr
     // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
     const int64_t t0 = (is_row ? 6 : 2) * (int64_t)p.N, t1 = (is_row ? 7 : 5) * (int64_t)p.N, t2 = 8 * (int64_t)p.N;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bool inb[5];
+    // unconditional loads at clamped positions (masked afterwards) so that the channel loop can be batched:
+    // 4 channels = 36 independent loads in flight per thread instead of one dependent round trip per channel
+    int64_t xoff[5];
+    float msk[5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) inb[t] = v0 + t >= 0 && v0 + t < L;
-    const int kper = (p.K + KG - 1) / KG;
+    for (int t = 0; t < 5; ++t) {
+        const int v = v0 + t;
+        msk[t] = (v >= 0 && v < L) ? 1.f : 0.f;
+        xoff[t] = fixed + (int64_t)(v < 0 ? 0 : (v >= L ? L - 1 : v)) * stride;
+    }
+    const int kper = (((p.K + KG - 1) / KG) + 3) & ~3;
     const int i_lo = kg * kper, i_hi = (i_lo + kper < p.K) ? i_lo + kper : p.K;
-#pragma unroll 4
-    for (int i = i_lo; i < i_hi; ++i) {
-        const float s = p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f;
-        const float* xp = p.x + ((int64_t)b * p.K + i) * in_plane + fixed + (int64_t)v0 * stride;
-        float xv[5];
+    const float* xb = p.x + (int64_t)b * p.K * in_plane;
+    const float* wb = p.wp + (ov ? o : 0);
+    for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
+        float xv[4][5], wv[4][3], sv[4];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) xv[t] = inb[t] ? s * xp[t * stride] : 0.f;
-        const float* wq = p.wp + (int64_t)i * 9 * p.N + (ov ? o : 0);
-        const float w0 = wq[t0], w1 = wq[t1], w2 = wq[t2];
+        for (int c = 0; c < 4; ++c) {
+            const int i = (i0 + c < p.K) ? i0 + c : p.K - 1;
+            sv[c] = (i0 + c < i_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f) : 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
-            acc[2 * t] += w0 * xv[t + 1] + w2 * xv[t];
-            acc[2 * t + 1] += w1 * xv[t + 1];
+            for (int t = 0; t < 5; ++t) xv[c][t] = xb[(int64_t)i * in_plane + xoff[t]];
+            const float* wq = wb + (int64_t)i * 9 * p.N;
+            wv[c][0] = wq[t0], wv[c][1] = wq[t1], wv[c][2] = wq[t2];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) xv[c][t] *= sv[c] * msk[t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
+                acc[2 * t] += wv[c][0] * xv[c][t + 1] + wv[c][2] * xv[c][t];
+                acc[2 * t + 1] += wv[c][1] * xv[c][t + 1];
+            }
         }
     }
 #pragma unroll
@@ -463,8 +503,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     const TileCfg* cfgs = kCfgStd;
     const int ncfg = kNumCfg;
     const int kc = mode == W2E_CONV_DOWN ? 4 : 8;
+    const int kc_max = up ? 16 : kc;  // deepest chunk any workgroup of this launch uses
     const int wp2 = next_pow2(w);
-    int best = -1;
+    int best = -1, best_splits = 1;
     double best_cost = 0.0;
     for (int c = 0; c < ncfg; ++c) {
         const int tn = 32 * cfgs[c].nob * cfgs[c].wo, tm = 32 * cfgs[c].npb * cfgs[c].wp;
@@ -473,21 +514,29 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         if (th < 1) continue;
         const int ph = mode == W2E_CONV_SAME ? th + 2 : (up ? th + 1 : 2 * th + 1);
         const int pw = mode == W2E_CONV_SAME ? tw + 2 : (up ? tw + 1 : 2 * tw + 1);
-        if (sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw) > 64 * 1024) continue;
+        const size_t lds_c = up ? sizeof(float) * ((size_t)32 * tn + (size_t)16 * ph * pw)
+                                : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw);
+        if (lds_c > 64 * 1024) continue;
         const int nt = 64 * cfgs[c].wo * cfgs[c].wp;
         if (ph * pw > nt * max_patch_slots(mode, tm, nt)) continue;  // register-prefetch slots per thread
         const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
         const double waves_per_simd = nt / 256.0;
         const double unit = (double)cfgs[c].nob * cfgs[c].npb * waves_per_simd * (k_ch / 2.0) * 64.0;  // one tap
         const double t_stage = (double)ceil_div(k_ch, kc) * 1200.0;
-        double cost;
-        if (up) {  // 4 phases with 4/2/2/1 taps, heaviest dispatched first
-            const double per_cu = ceil(4.0 * tiles / 256.0) / 4.0;  // tiles (sets of 4 phases) per CU
-            cost = per_cu * (9.0 * unit + 4.0 * t_stage) + (4.0 * tiles < 1024.0 ? 1.75 * unit : 0.0);
-        } else {
-            cost = ceil(tiles / 256.0) * (9.0 * unit + t_stage);
+        // split-K (low resolutions: a handful of tiles, each a K*9/2-long dependent MFMA chain): S slices of the
+        // channel range per tile, summed with fp32 atomics onto a zeroed output
+        for (int sp = 1; sp <= 32; sp *= 2) {
+            if (sp > 1 && (k_ch / sp < 2 * kc_max || (up ? 4.0 : 1.0) * tiles * (sp / 2) >= 256.0)) break;
+            double cost;
+            if (up) {  // 4 phases with 4/2/2/1 taps, heaviest dispatched first
+                const double per_cu = ceil(4.0 * tiles * sp / 256.0) / 4.0;  // tile-slices (sets of 4 phases) per CU
+                cost = per_cu * ((9.0 * unit + 4.0 * t_stage) / sp + 16000.0) + (4.0 * tiles * sp < 1024.0 ? 1.75 * unit / sp : 0.0);
+            } else {
+                cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + t_stage) / sp + 4000.0);  // + prologue/epilogue per workgroup
+            }
+            if (sp > 1) cost += 6000.0;  // memset + atomics + (with act) the separate bias/act pass
+            if (best < 0 || cost < best_cost * 0.97) best = c, best_cost = cost, best_splits = sp;
         }
-        if (best < 0 || cost < best_cost * 0.97) best = c, best_cost = cost;
     }
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
@@ -503,14 +552,22 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     p.plane = p.ph * p.pw;
     p.pw_magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)p.pw + 1);
     W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
-    const size_t lds = sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
+    const size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)16 * p.plane)
+                          : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     W2E_REQUIRE(lds <= 64 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
-    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * (up ? 4 : 1);
+    p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), kc_max) * kc_max);
+    p.splits = (int)ceil_div(k_ch, p.k_per);
+    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * (up ? 4 : 1) * p.splits;
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
+    if (p.splits > 1 &&
+        hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * p.out_h * p.out_w, s) != hipSuccess) {
+        set_error("modconv3x3: memset failed");
+        return 2;
+    }
     bool ok = false;
     if (mode == W2E_CONV_SAME) {
-        if (act) ok = launch_mode<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
+        if (act && p.splits == 1) ok = launch_mode<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
         else if (dot_with) ok = launch_mode<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
         else ok = launch_mode<W2E_CONV_SAME, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
     } else if (up) {
@@ -521,6 +578,10 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     }
     W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
     W2E_LAUNCH_CHECK("modconv3x3");
+    if (act && p.splits > 1) {  // the activation needs the complete sum: one in-place elementwise pass
+        const int rc = w2e_bias_act_fwd(y, bias, noise, noise_w, y, batch, n_ch, (int64_t)h * w, 0.2f, 1.4142135623730951f, stream);
+        if (rc != 0) return rc;
+    }
     if (up) {
         const int groups_row = (int)ceil_div(2 * w + 1, 8), groups_col = (int)ceil_div(2 * h, 8);
         if (n_ch >= 64) {

@@ -28,6 +28,7 @@ struct GemmParams {
     const float* bias;
     const float* residual;
     const float* aux;
+    int k_per;  // K range of one blockIdx.z slice (split-K); == k when gridDim.z == 1
 };
 
 template <bool TRANS_B, bool A_GELU>
@@ -79,12 +80,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
     };
 
-    prefetch(0);
-    for (int k0 = 0; k0 < p.k; k0 += GBK) {
+    const int k_lo = blockIdx.z * p.k_per;
+    const int k_hi = (k_lo + p.k_per < p.k) ? k_lo + p.k_per : p.k;
+    prefetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += GBK) {
         __syncthreads();
         commit();
         __syncthreads();
-        if (k0 + GBK < p.k) prefetch(k0 + GBK);
+        if (k0 + GBK < k_hi) prefetch(k0 + GBK);
         const float* ap = As + (wm * 32 + j) * GPA + half;
         const float* bp = TRANS_B ? Bs + (wn * 32 + j) * GPA + half : Bs + half * GBN + wn * 32 + j;
 #pragma unroll
@@ -96,16 +99,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
     const int n = n0 + wn * 32 + j;
     if (n >= p.n) return;
-    const float bs = p.bias ? p.bias[n] : 0.f;
+    const bool first = blockIdx.z == 0;  // split-K: slice 0 carries bias + residual, every slice adds atomically
+    const float bs = (p.bias && first) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= p.m) continue;
         const int64_t ci = (int64_t)m * p.ldc + n;
         float v = acc[r] + bs;
-        if (p.residual) v += p.residual[ci];
-        if (p.aux) v *= quick_gelu_grad(p.aux[ci]);
-        p.c[ci] = v;
+        if (p.residual && first) v += p.residual[ci];
+        if (gridDim.z > 1) {
+            atomicAdd(&p.c[ci], v);
+        } else {
+            if (p.aux) v *= quick_gelu_grad(p.aux[ci]);
+            p.c[ci] = v;
+        }
     }
 }
 
@@ -309,9 +317,22 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     W2E_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "gemm: operands must be 16-byte aligned");
     W2E_REQUIRE(!(a_gelu && !trans_b), "gemm: the QuickGELU prologue is implemented for the [N,K] form only");
     if (m == 0) return 0;
-    GemmParams p{a, b, c, m, n, k, lda, ldb, ldc, bias, residual, gelu_grad_aux};
-    dim3 grid((unsigned)ceil_div(n, GBN), (unsigned)ceil_div(m, GBM));
     hipStream_t s = (hipStream_t)stream;
+    // Small-M GEMMs (M = 50*batch) leave most CUs idle with one workgroup per 64x64 tile and make every wave a
+    // K/2-long dependent MFMA chain: split K over blockIdx.z (fp32 atomics onto a zeroed C) until the grid fills the chip.
+    const int64_t tiles = ceil_div(n, GBN) * ceil_div(m, GBM);
+    int splits = 1;
+    if (!gelu_grad_aux && ldc == n) {
+        while (tiles * splits < 256 && splits < 8 && k / (splits * 2) >= 256) splits *= 2;
+    }
+    const int k_per = (int)(ceil_div(ceil_div(k, splits), GBK) * GBK);
+    splits = (int)ceil_div(k, k_per);
+    if (splits > 1 && hipMemsetAsync(c, 0, sizeof(float) * (size_t)m * n, s) != hipSuccess) {
+        set_error("gemm: memset failed");
+        return 2;
+    }
+    GemmParams p{a, b, c, m, n, k, lda, ldb, ldc, bias, residual, gelu_grad_aux, k_per};
+    dim3 grid((unsigned)ceil_div(n, GBN), (unsigned)ceil_div(m, GBM), (unsigned)splits);
     if (trans_b) {
         if (a_gelu) gemm_kernel<true, true><<<grid, 256, 0, s>>>(p);
         else gemm_kernel<true, false><<<grid, 256, 0, s>>>(p);
