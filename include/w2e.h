@@ -84,6 +84,15 @@ int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_sc
                    float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
                    const float* noise_w, const float* bias, const float* dot_with, float* dot_out, void* stream);
 
+/* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
+ *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */
+int w2e_demod_fwd(const float* s, const float* wsq, float* d, int batch, int cin, int cout, float eps, void* stream);
+/* gs[b,i] -= s[b,i] * sum_o dz[b,o]*d[b,o]^2*wsq[o,i]  (gs holds the direct part sum_p x*g on entry), where
+ * dz[b,o] = sum_p gpre*(d*z) is either given (`dz`) or rebuilt from w2e_bias_act_bwd_reduce's `sums` as
+ * s1 - noise_w*s2 - bias[o]*s3.  Exactly one of sums / dz is non-NULL.  gd (optional) receives dz/d. */
+int w2e_demod_bwd(const float* sums, const float* dz, const float* noise_w, const float* bias, const float* d,
+                  const float* s, const float* wsq, float* gs, float* gd, int batch, int cin, int cout, void* stream);
+
 /* ---- K1r  ToRGB: modulated 1x1 conv (no demod) + bias + upsampled skip  (model.py:343-362) --
  * wmod [B,3,cin] = scale*W[c,i]*s[b,i] (tiny, built by the host);  skip [B,3,h/2,w/2] or NULL is
  * up-sampled x2 with the 4x4 kernel `upk` (Upsample, model.py:31-49: up=2, pad (2,1)) and added. */

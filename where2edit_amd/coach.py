@@ -28,6 +28,10 @@ class Coach:
         self.device = device if device is not None else "cuda:0"  # coach.py:25
         self.opts.device = self.device
         self.net = (net if net is not None else StyleCLIPMapper(self.opts)).to(self.device)
+        # The decoder is never optimised (configure_optimizers: mapper parameters only, coach.py:174-180).  The
+        # reference nevertheless leaves requires_grad=True on it and pays for ~30 M unused weight gradients per
+        # step; here it is frozen, which changes no result the loop can observe.
+        self.net.decoder.requires_grad_(False)
         if self.opts.id_lambda > 0:
             if id_loss is None:
                 from .id_loss import IDLoss

@@ -243,6 +243,57 @@ __global__ void clip_preproc_bwd_kernel(const float* __restrict__ gout, float* _
     }
 }
 
+// ------------------------------------------------------------------------------------- demodulation
+// d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps)   (model.py:241-243 with wsq = sum_k (scale*W)^2).
+// One wave per (b,o).
+__global__ __launch_bounds__(256) void demod_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq,
+                                                        float* __restrict__ d, int B, int Cin, int Cout, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * Cout) return;
+    const int b = row / Cout, o = row - b * Cout;
+    float acc = 0.f;
+    for (int i = lane; i < Cin; i += 64) {
+        const float v = s[(int64_t)b * Cin + i];
+        acc += v * v * wsq[(int64_t)o * Cin + i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) d[row] = rsqrtf(acc + eps);
+}
+
+// Style gradient through the demodulation, added onto the direct part already in gs:
+//   dz[b,o] = sum_p gpre * (d*z)  (= s1 - nw*s2 - bias*s3 from the fused-activation reductions, or given)
+//   gd = dz / d;  dd/ds[b,i] = -d^3 * wsq[o,i] * s[b,i]   =>   gs[b,i] += -s[b,i] * sum_o dz[b,o]*d[b,o]^2*wsq[o,i]
+// Block = (b, 256 input channels): coefficients in LDS, threads over i (coalesced wsq rows).
+__global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ dz_in,
+                                                        const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                        const float* __restrict__ d, const float* __restrict__ s,
+                                                        const float* __restrict__ wsq, float* __restrict__ gs,
+                                                        float* __restrict__ gd_out, int Cin, int Cout) {
+    extern __shared__ float coef[];  // [Cout]
+    const int b = blockIdx.y;
+    const float nw = noise_w ? noise_w[0] : 0.f;
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        float dz;
+        if (sums) {
+            const float* q = sums + ((int64_t)b * Cout + o) * 3;
+            dz = q[0] - nw * q[1] - (bias ? bias[o] : 0.f) * q[2];
+        } else {
+            dz = dz_in[(int64_t)b * Cout + o];
+        }
+        const float dv = d[(int64_t)b * Cout + o];
+        coef[o] = dz * dv * dv;
+        if (gd_out && blockIdx.x == 0) gd_out[(int64_t)b * Cout + o] = dz / dv;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cin) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < Cout; ++o) acc += coef[o] * wsq[(int64_t)o * Cin + i];
+    gs[(int64_t)b * Cin + i] -= s[(int64_t)b * Cin + i] * acc;
+}
+
 }  // namespace w2e
 
 using namespace w2e;
@@ -354,6 +405,27 @@ int w2e_clip_preproc_bwd(const float* gout, float* gimg, int64_t planes, int siz
     if (total <= 0) return 0;
     clip_preproc_bwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gout, gimg, total, size, size / 32);
     W2E_LAUNCH_CHECK("clip_preproc_bwd");
+    return 0;
+}
+
+int w2e_demod_fwd(const float* s, const float* wsq, float* d, int batch, int cin, int cout, float eps, void* stream) {
+    W2E_REQUIRE(s && wsq && d, "demod_fwd: null tensor");
+    W2E_REQUIRE(batch >= 0 && cin > 0 && cout > 0, "demod_fwd: bad dims");
+    if (batch == 0) return 0;
+    demod_fwd_kernel<<<(unsigned)ceil_div((int64_t)batch * cout, 4), 256, 0, (hipStream_t)stream>>>(s, wsq, d, batch, cin, cout, eps);
+    W2E_LAUNCH_CHECK("demod_fwd");
+    return 0;
+}
+
+int w2e_demod_bwd(const float* sums, const float* dz, const float* noise_w, const float* bias, const float* d,
+                  const float* s, const float* wsq, float* gs, float* gd, int batch, int cin, int cout, void* stream) {
+    W2E_REQUIRE((sums != nullptr) != (dz != nullptr), "demod_bwd: give exactly one of sums / dz");
+    W2E_REQUIRE(d && s && wsq && gs, "demod_bwd: null tensor");
+    W2E_REQUIRE(batch >= 0 && cin > 0 && cout > 0 && batch < 65536, "demod_bwd: bad dims");
+    if (batch == 0) return 0;
+    dim3 grid((unsigned)ceil_div(cin, 256), (unsigned)batch);
+    demod_bwd_kernel<<<grid, 256, sizeof(float) * cout, (hipStream_t)stream>>>(sums, dz, noise_w, bias, d, s, wsq, gs, gd, cin, cout);
+    W2E_LAUNCH_CHECK("demod_bwd");
     return 0;
 }
 

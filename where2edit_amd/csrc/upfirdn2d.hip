@@ -41,58 +41,130 @@ constexpr int MAX_TILE_K = 8;    // taps per axis the tile kernel handles (pitch
 // up = down = 1.  The (TH+kh-1) x (TW+kw-1) input tile is staged once into LDS (row pitch a multiple of 4
 // floats so each thread's window rows are 16-B aligned: ds_read_b128), every thread then slides the taps
 // over a register window: 2*(kw+3) LDS floats read per 8 outputs.
+// 4x4 FIR (the generator's blur), up = down = 1: taps in registers, everything unrolled, ACT compile-time.
+template <bool ACT>
+__global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;
+    constexpr int PW = TW + 3, PH = TH + 3, PITCH = (PW + 3) & ~3;
+    const int tid = threadIdx.x;
+    float kr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kr[i] = p.flip ? p.kern[15 - i] : p.kern[i];
+    const float nw = (ACT && p.noise) ? p.noise_w[0] : 0.f;
+    const int tiles_per_plane = tiles_x * tiles_y;
+    const int n_tiles = tiles_per_plane * (int)p.planes;
+    const int ly = (tid >> 4) * 2, lx = (tid & 15) * 4;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int plane = t / tiles_per_plane;
+        const int rem = t - plane * tiles_per_plane;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const float* src = p.x + (int64_t)plane * p.in_h * p.in_w;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
+        __syncthreads();  // previous iteration's readers are done
+#pragma unroll
+        for (int it = 0; it < (PH * PW + 255) / 256; ++it) {
+            const int i = tid + it * 256;
+            const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * PW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            // branch-free: load from a clamped (always valid) address, then select
+            const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
+            const float v = src[cy * p.in_w + cx];
+            if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
+        }
+        __syncthreads();
+        float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {  // input row ly+r feeds output row 0 with ky=r and output row 1 with ky=r-1
+            const float4 a = *reinterpret_cast<const float4*>(tile + (ly + r) * PITCH + lx);
+            const float4 b = *reinterpret_cast<const float4*>(tile + (ly + r) * PITCH + lx + 4);
+            const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (r < 4) acc0[j] += kr[r * 4 + kx] * win[kx + j];
+                    if (r >= 1) acc1[j] += kr[(r - 1) * 4 + kx] * win[kx + j];
+                }
+            }
+        }
+        const int ox = ox0 + lx;
+        float e_scale = 1.f, e_bias = 0.f;
+        if (ACT) {
+            if (p.out_scale) e_scale = p.out_scale[plane];
+            if (p.bias) e_bias = p.bias[plane % p.channels];
+        }
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+            const int oy = oy0 + ly + yy;
+            if (oy >= p.out_h || ox >= p.out_w) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float e = yy ? acc1[j] : acc0[j];
+                if (ACT) {
+                    e = e * e_scale + e_bias;
+                    if (p.noise) e += nw * p.noise[oy * p.out_w + (ox + j < p.out_w ? ox + j : ox)];
+                    e = (e > 0.f ? e : e * p.slope) * p.gain;
+                }
+                v[j] = e;
+            }
+            float* dst = p.y + ((int64_t)plane * p.out_h + oy) * p.out_w + ox;
+            if (ox + 3 < p.out_w && (p.out_w & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < p.out_w) dst[j] = v[j];
+            }
+        }
+    }
+}
+
+// General tap counts (<= MAX_TILE_K per axis), up = down = 1.
 __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* kbuf = smem;  // kh*kw taps, already oriented for correlation
     float* tile = smem + MAXK * MAXK;
-    const int pw = TW + p.kw - 1, ph = TH + p.kh - 1;
+    const int kh = p.kh, kw = p.kw;
+    const int pw = TW + kw - 1, ph = TH + kh - 1;
     const int pitch = (pw + 3) & ~3;
     const int tid = threadIdx.x;
-    for (int i = tid; i < p.kh * p.kw; i += 256) {
-        const int ky = i / p.kw, kx = i % p.kw;
-        kbuf[i] = p.flip ? p.kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : p.kern[i];
+    for (int i = tid; i < kh * kw; i += 256) {
+        const int ky = i / kw, kx = i % kw;
+        kbuf[i] = p.flip ? p.kern[(kh - 1 - ky) * kw + (kw - 1 - kx)] : p.kern[i];
     }
     const float nw = (p.act && p.noise) ? p.noise_w[0] : 0.f;
-    const int64_t n_tiles = (int64_t)tiles_x * tiles_y * p.planes;
+    const int tiles_per_plane = tiles_x * tiles_y;
+    const int n_tiles = tiles_per_plane * (int)p.planes;
     const int ly = (tid >> 4) * 2, lx = (tid & 15) * 4;
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int tx = (int)(t % tiles_x);
-        const int ty = (int)((t / tiles_x) % tiles_y);
-        const int64_t plane = t / ((int64_t)tiles_x * tiles_y);
-        const float* src = p.x + plane * (int64_t)p.in_h * p.in_w;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int plane = t / tiles_per_plane;
+        const int rem = t - plane * tiles_per_plane;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const float* src = p.x + (int64_t)plane * p.in_h * p.in_w;
         const int oy0 = ty * TH, ox0 = tx * TW;
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
-        __syncthreads();  // previous iteration's readers are done (also orders the kbuf fill)
+        __syncthreads();
         for (int i = tid; i < ph * pw; i += 256) {
             const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * pw;
             const int iy = iy0 + r, ix = ix0 + c;
-            tile[r * pitch + c] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? src[(int64_t)iy * p.in_w + ix] : 0.f;
+            tile[r * pitch + c] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? src[iy * p.in_w + ix] : 0.f;
         }
         __syncthreads();
         float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        for (int r = 0; r < p.kh + 1; ++r) {  // input rows ly+r feed output row 0 with ky=r and row 1 with ky=r-1
-            float win[4 + MAX_TILE_K - 1 + 1];
-            const float4* rp = reinterpret_cast<const float4*>(tile + (ly + r) * pitch + lx);
+        for (int r = 0; r < kh + 1; ++r) {
+            const float* rp = tile + (ly + r) * pitch + lx;
+            for (int kx = 0; kx < kw; ++kx) {
+                const float k0 = r < kh ? kbuf[r * kw + kx] : 0.f;
+                const float k1 = r >= 1 ? kbuf[(r - 1) * kw + kx] : 0.f;
 #pragma unroll
-            for (int q = 0; q < (4 + MAX_TILE_K - 1 + 3) / 4; ++q) {
-                if (q * 4 < 4 + p.kw - 1) {
-                    const float4 v = rp[q];
-                    win[q * 4] = v.x, win[q * 4 + 1] = v.y, win[q * 4 + 2] = v.z, win[q * 4 + 3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int kx = 0; kx < MAX_TILE_K; ++kx) {
-                if (kx < p.kw) {
-                    if (r < p.kh) {
-                        const float k0 = kbuf[r * p.kw + kx];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[0][j] += k0 * win[kx + j];
-                    }
-                    if (r >= 1) {
-                        const float k1 = kbuf[(r - 1) * p.kw + kx];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[1][j] += k1 * win[kx + j];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float v = rp[kx + j];
+                    acc[0][j] += k0 * v;
+                    acc[1][j] += k1 * v;
                 }
             }
         }
@@ -101,17 +173,10 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int 
         for (int yy = 0; yy < 2; ++yy) {
             const int oy = oy0 + ly + yy;
             if (oy >= p.out_h || ox >= p.out_w) continue;
-            float* dst = p.y + (plane * p.out_h + oy) * (int64_t)p.out_w + ox;
-            float v[4];
+            float* dst = p.y + ((int64_t)plane * p.out_h + oy) * p.out_w + ox;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = epilogue(p, acc[yy][j], plane, oy, ox + j < p.out_w ? ox + j : ox, nw);
-            if (ox + 3 < p.out_w && (p.out_w & 3) == 0) {
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ox + j < p.out_w) dst[j] = v[j];
-            }
+            for (int j = 0; j < 4; ++j)
+                if (ox + j < p.out_w) dst[j] = epilogue(p, acc[yy][j], plane, oy, ox + j, nw);
         }
     }
 }
@@ -170,11 +235,17 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     if (up == 1 && down == 1 && out_w >= 32 && kh <= MAX_TILE_K && kw <= MAX_TILE_K) {
         const int tiles_x = (int)ceil_div(out_w, TW), tiles_y = (int)ceil_div(out_h, TH);
         const int64_t n_tiles = planes * tiles_x * tiles_y;
+        W2E_REQUIRE(n_tiles < ((int64_t)1 << 31) && (int64_t)in_h * in_w < ((int64_t)1 << 31), "upfirdn2d: tensor too large");
         const int pw = TW + kw - 1, pitch = (pw + 3) & ~3;
         const size_t lds = sizeof(float) * (MAXK * MAXK + (size_t)(TH + kh) * pitch + 16);
         const int grid = (int)(n_tiles < 16384 ? n_tiles : 16384);
         const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)pw + 1);
-        upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+        if (kh == 4 && kw == 4) {
+            if (act) upfirdn_tile4_kernel<true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+            else upfirdn_tile4_kernel<false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+        } else {
+            upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+        }
     } else {
         upfirdn_generic_kernel<<<stream_grid(total, 256), 256, 0, s>>>(p, total);
     }

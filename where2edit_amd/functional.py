@@ -147,19 +147,28 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     return y, dot
 
 
+def demod_coefficients(s, wsq, eps=1e-8):
+    """d[b,o] = rsqrt(sum_i s[b,i]^2 wsq[o,i] + eps) (w2e_demod_fwd)."""
+    b, cin = s.shape
+    cout = wsq.shape[0]
+    d = torch.empty((b, cout), device=s.device, dtype=torch.float32)
+    call("w2e_demod_fwd", ptr(s), ptr(wsq), ptr(d), b, cin, cout, float(eps), stream_ptr())
+    return d
+
+
 class _StyledConv(torch.autograd.Function):
-    """Fused StyledConv: out = lrelu(d * conv(Wp, s*x) [blur] + nw*noise + bias) * sqrt2
-    (model.py:234-276, 285-290, op/fused_act.py); with fuse_act=False just d * conv(Wp, s*x) [blur]
-    (a bare ModulatedConv2d).  Differentiable in x, s, d, noise_w, bias.
-    The conv weight is treated as frozen (no weight gradient is produced -- the decoder is never
-    optimised on this path: coach.py:174-180 optimises net.mapper only)."""
+    """Fused StyledConv: out = lrelu(d * conv(Wp, s*x) [blur] + nw*noise + bias) * sqrt2 with
+    d = rsqrt(s^2 @ wsq^T + eps) (model.py:234-276, 285-290, op/fused_act.py); with fuse_act=False just
+    d * conv(Wp, s*x) [blur] (a bare ModulatedConv2d).  Differentiable in x, s (direct + demodulation paths in one
+    gradient), noise_w, bias.  The conv weight is treated as frozen (no weight gradient is produced -- the decoder is
+    never optimised on this path: coach.py:174-180 optimises net.mapper only)."""
 
     @staticmethod
-    def forward(ctx, x, s, d, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act):
+    def forward(ctx, x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act):
         x, s = _c(x), _c(s)
-        d = _c(d) if d is not None else None
         b, cin, h, w = x.shape
         wp_f, wp_b = packs
+        d = demod_coefficients(s, wsq) if wsq is not None else None
         act = (noise, noise_w, bias) if fuse_act else None
         if upsample:
             t, _ = _modconv_raw(MODE_UP, x, wp_f, s, d, h, w)
@@ -167,34 +176,32 @@ class _StyledConv(torch.autograd.Function):
                                  act=((None,) + act) if fuse_act else None)
         else:
             out, _ = _modconv_raw(MODE_SAME, x, wp_f, s, d, h, w, act=act)
-        ctx.save_for_backward(x, s, d, noise, noise_w, bias, out, wp_b, blur_kernel)
+        ctx.save_for_backward(x, s, d, wsq, noise, noise_w, bias, out, wp_b, blur_kernel)
         ctx.cfg = (upsample, fuse_act)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        x, s, d, noise, noise_w, bias, out, wp_b, blur_kernel = ctx.saved_tensors
+        x, s, d, wsq, noise, noise_w, bias, out, wp_b, blur_kernel = ctx.saved_tensors
         upsample, fuse_act = ctx.cfg
         b, cin, h, w = x.shape
         cout, oh, ow = out.shape[1], out.shape[2], out.shape[3]
         gout = _c(gout)
-        g_bias = g_nw = None
+        g_bias = g_nw = sums = dz = None
         if fuse_act:
             gpre = torch.empty_like(out)
             sums = torch.empty((b, cout, 3), device=x.device, dtype=torch.float32)
             call("w2e_bias_act_bwd_reduce", ptr(gout), ptr(out), ptr(noise), ptr(gpre), ptr(sums), b, cout, oh * ow,
                  0.2, SQRT2, stream_ptr())
-            s1, s2, s3 = sums[..., 0], sums[..., 1], sums[..., 2]
-            nw = noise_w if noise is not None else None
-            # sum_p gpre * (d*z) with d*z = pre - nw*noise - bias
-            dz = s1 - (nw * s2 if nw is not None else 0) - (bias.view(1, -1) * s3 if bias is not None else 0)
-            g_bias = s3.sum(0) if bias is not None else None
-            g_nw = s2.sum().reshape(1) if nw is not None else None
+            if bias is not None and ctx.needs_input_grad[5]:
+                g_bias = sums[..., 2].sum(0)
+            if noise is not None and ctx.needs_input_grad[4]:
+                g_nw = sums[..., 1].sum().reshape(1)
         else:
             gpre = gout
-            dz = (gout * out).sum((2, 3)) if d is not None else None
-        gd = dz / d if d is not None else None
+            if d is not None:
+                dz = (gout * out).sum((2, 3))
         if upsample:
             # adjoint of Blur(pad=(1,1)) back onto the (2h+1)x(2w+1) transposed-conv grid, then the
             # stride-2 conv that is the adjoint of conv_transpose2d
@@ -202,16 +209,19 @@ class _StyledConv(torch.autograd.Function):
             gx, gs = _modconv_raw(MODE_DOWN, gt, wp_b, d, s, h, w, dot_with=x)
         else:
             gx, gs = _modconv_raw(MODE_SAME, gpre, wp_b, d, s, h, w, dot_with=x)
-        return gx, gs, gd, None, g_nw, g_bias, None, None, None, None
+        if d is not None:  # + the demodulation path: gs -= s * (dz*d^2) @ wsq, with dz = sum_p gpre*(pre - nw*noise - bias)
+            call("w2e_demod_bwd", ptr(sums), ptr(dz), ptr(noise_w) if (fuse_act and noise is not None) else None,
+                 ptr(bias) if fuse_act else None, ptr(d), ptr(s), ptr(wsq), ptr(gs), None, b, cin, cout, stream_ptr())
+        return gx, gs, None, None, g_nw, g_bias, None, None, None, None
 
 
-def styled_conv(x, s, d, noise, noise_w, bias, packs, blur_kernel, upsample):
-    return _StyledConv.apply(x, s, d, noise, noise_w, bias, packs, blur_kernel, upsample, True)
+def styled_conv(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample):
+    return _StyledConv.apply(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, True)
 
 
-def modconv(x, s, d, packs, blur_kernel, upsample):
+def modconv(x, s, wsq, packs, blur_kernel, upsample):
     """Bare ModulatedConv2d (3x3): d * conv(Wp, s*x), with the FIR blur for the up-sampling variant."""
-    return _StyledConv.apply(x, s, d, None, None, None, packs, blur_kernel, upsample, False)
+    return _StyledConv.apply(x, s, wsq, None, None, None, packs, blur_kernel, upsample, False)
 
 
 def modconv_down_plain(x, s, d, wp_f, h, w):

@@ -119,11 +119,24 @@ class EqualLinear(nn.Module):
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
 
+    def _scaled(self):
+        """weight*scale and bias*lr_mul (model.py:151-158).  For frozen parameters (the decoder on the mapper path)
+        the products are cached until the parameters change instead of being recomputed by two kernels per call."""
+        w, b = self.weight, self.bias
+        if torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad)):
+            return w * self.scale, (b * self.lr_mul if b is not None else None)
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+        if getattr(self, "_scaled_key", None) != key:
+            with torch.no_grad():
+                self._scaled_val = ((w * self.scale).detach(), (b * self.lr_mul).detach() if b is not None else None)
+            self._scaled_key = key
+        return self._scaled_val
+
     def forward(self, input):
+        w, b = self._scaled()
         if self.activation:
-            out = F.linear(input, self.weight * self.scale)
-            return fused_leaky_relu(out, self.bias * self.lr_mul)
-        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+            return fused_leaky_relu(F.linear(input, w), b)
+        return F.linear(input, w, bias=b)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
@@ -198,12 +211,6 @@ class ModulatedConv2d(nn.Module):
             style = self.modulation(style).view(batch, 1, self.in_channel, 1, 1)
         return style
 
-    def _demod(self, s2d, wsq):
-        """demod[b,o] = rsqrt(sum_{i,k} (scale*W[o,i,k]*s[b,i])^2 + eps) = rsqrt(s^2 @ wsq^T + eps) (model.py:241-243)."""
-        if not self.demodulate:
-            return None
-        return torch.rsqrt(F.linear(s2d * s2d, wsq) + self.eps)
-
     def forward(self, input, style, input_is_stylespace=False):
         if self.kernel_size not in (1, 3):
             raise NotImplementedError("ModulatedConv2d kernels exist for kernel_size 1 and 3 (the sizes the generator uses)")
@@ -211,16 +218,18 @@ class ModulatedConv2d(nn.Module):
         style = self._style(style, batch, input_is_stylespace)
         s2d = style.reshape(batch, in_channel)
         fwd, bwd, wsq = self._derived()
-        d = self._demod(s2d, wsq)
+        if not self.demodulate:
+            wsq = None  # demod[b,o] = rsqrt(s^2 @ wsq^T + eps) is computed inside the kernels (model.py:241-243)
         if self.downsample:
             if torch.is_grad_enabled() and (input.requires_grad or style.requires_grad):
                 raise NotImplementedError("down-sampling ModulatedConv2d (no caller in the generator) is forward-only")
             x = self.blur(input)
+            d = K.demod_coefficients(s2d.contiguous(), wsq) if wsq is not None else None
             out = K.modconv_down_plain(x, s2d, d, fwd, (x.shape[2] - 1) // 2, (x.shape[3] - 1) // 2)
         else:
             if self.upsample and (self.kernel_size != 3 or tuple(self.blur.kernel.shape) != (4, 4)):
                 raise NotImplementedError("up-sampling ModulatedConv2d: kernel_size 3 with a 4-tap blur")
-            out = K.modconv(input, s2d, d, (fwd, bwd), self.blur.kernel if self.upsample else None, self.upsample)
+            out = K.modconv(input, s2d, wsq, (fwd, bwd), self.blur.kernel if self.upsample else None, self.upsample)
         return out, style
 
 
@@ -274,8 +283,7 @@ class StyledConv(nn.Module):
         style = conv._style(style, batch, input_is_stylespace)
         s2d = style.reshape(batch, conv.in_channel)
         fwd, bwd, wsq = conv._derived()
-        d = conv._demod(s2d, wsq)
-        out = K.styled_conv(input, s2d, d, noise.contiguous(), self.noise.weight, self.activate.bias, (fwd, bwd),
+        out = K.styled_conv(input, s2d, wsq if conv.demodulate else None, noise.contiguous(), self.noise.weight, self.activate.bias, (fwd, bwd),
                             conv.blur.kernel if conv.upsample else None, conv.upsample)
         return out, style
 
