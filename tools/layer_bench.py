@@ -33,12 +33,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", type=str, default="", help="comma list of layer indices")
     args = ap.parse_args()
     B = args.batch
     dev = "cuda"
     tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
     print(f"{'layer':28s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s}")
-    for cin, cout, h, up in LAYERS:
+    sel = [int(i) for i in args.only.split(',')] if args.only else range(len(LAYERS))
+    for cin, cout, h, up in [LAYERS[i] for i in sel]:
         w = torch.randn(cout, cin, 3, 3, device=dev)
         scale = (cin * 9) ** -0.5
         fwd = K.conv_pack(w, scale, False, False)

@@ -16,7 +16,7 @@ _F = ctypes.c_float
 _PROTOS = {
     "w2e_version": (_I, []),
     "w2e_last_error": (ctypes.c_char_p, []),
-    "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
+    "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
     "w2e_bias_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
     "w2e_bias_act_bwd": (_I, [_P, _P, _P, _L, _F, _F, _P]),
     "w2e_bias_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),

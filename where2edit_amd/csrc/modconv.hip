@@ -22,6 +22,7 @@
 // stuffed image are never multiplied and the weight bytes staged per MFMA equal SAME's), DOWN (stride-2
 // conv = adjoint of UP).
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -50,6 +51,7 @@ struct ConvParams {
     int tiles_x, tiles_y, tiles_n;
     int ph, pw, plane;
     unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
+    int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
 };
 
@@ -57,8 +59,8 @@ enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
 
 // Upper bound of ceil(patch / threads) for a tile of `tm` pixels (the host refuses geometries beyond it).
 __host__ __device__ constexpr int max_patch_slots(int mode, int tm, int nt) {
-    return mode == W2E_CONV_DOWN ? (nt == 512 ? (tm >= 1024 ? 9 : 5) : (tm >= 256 ? 5 : (tm >= 128 ? 3 : (tm >= 64 ? 2 : 1))))
-                                 : (nt == 512 ? (tm >= 2048 ? 5 : (tm >= 1024 ? 3 : 2)) : (tm >= 256 ? 2 : 1));
+    return mode == W2E_CONV_DOWN ? (nt == 512 ? (tm >= 1024 ? 9 : 5) : (tm >= 512 ? 9 : (tm >= 256 ? 5 : (tm >= 128 ? 3 : (tm >= 64 ? 2 : 1)))))
+                                 : (nt == 512 ? (tm >= 2048 ? 5 : (tm >= 1024 ? 3 : 2)) : (tm >= 512 ? 3 : (tm >= 256 ? 2 : 1)));
 }
 
 // Tap bookkeeping.  SAME/DOWN use all 9 taps.  An UP workgroup owns ONE output phase (PY,PX) and only its taps
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int ks = bid % p.splits;
     bid /= p.splits;
     const int k_lo = ks * p.k_per;
-    const int k_hi = (k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K;
+    const int k_hi = (p.tune_skip & 2) ? k_lo : ((k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K);
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -284,42 +286,71 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         gx[pb] = c0 + lx;
         valid[pb] = ly < p.th && gy[pb] < p.H && gx[pb] < p.W;
     }
+    // CDNA4's vmcnt counts loads AND stores in order, so a load issued after a store cannot be consumed before
+    // that store has completed: every value the epilogue reads from memory is loaded BEFORE its first store.
+    // Offsets are 32-bit (host checks the tensors are < 2^31 elements).
+    int pix[NPB];  // element offset of the lane's pixel inside one (b, o) output plane
+    float nz[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+        // UP writes its phase plane of the phase-planar image [4][H+1][W+1]: unit-stride rows
+        if (MODE == W2E_CONV_UP) pix[pb] = (phase * (p.H + 1) + gy[pb]) * (p.W + 1) + gx[pb];
+        else pix[pb] = gy[pb] * p.out_w + gx[pb];
+        nz[pb] = (EPI == EPI_ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
+    }
+    const int out_plane = (MODE == W2E_CONV_UP) ? 4 * (p.H + 1) * (p.W + 1) : p.out_h * p.out_w;
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
+        float os[16], bs[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ol = (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int o = n0 + ol;
-            const bool ov = o < p.N;
-            const float os = (ov && p.out_scale) ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
-            const float bs = (EPI == EPI_ACT && ov && p.bias) ? p.bias[o] : 0.f;
-            float dsum = 0.f;
+            const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            os[r] = (o < p.N && p.out_scale) ? p.out_scale[b * p.N + o] : 1.f;
+            bs[r] = (EPI == EPI_ACT && o < p.N && p.bias) ? p.bias[o] : 0.f;
+        }
+        if (EPI == EPI_DOT) {  // pass 1: loads + reductions only, 8 rows (8*NPB loads in flight per lane) at a time
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) {
-                if (!(ov && valid[pb])) continue;
-                {
-                    float v = acc[ob][pb][r];
-                    int64_t oi;
-                    if (MODE == W2E_CONV_UP) {
-                        const int Y = 2 * gy[pb] + (phase >> 1), X = 2 * gx[pb] + (phase & 1);
-                        oi = (((int64_t)b * p.N + o) * p.out_h + Y) * p.out_w + X;
-                    } else {
-                        oi = (((int64_t)b * p.N + o) * p.out_h + gy[pb]) * p.out_w + gx[pb];
-                    }
-                    if (EPI == EPI_DOT) dsum += v * p.dot_with[oi];
-                    v *= os;
-                    if (EPI == EPI_ACT) {
-                        v += bs + (p.noise ? nw * p.noise[(int64_t)gy[pb] * p.out_w + gx[pb]] : 0.f);
-                        v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
-                    }
-                    if (p.splits > 1) atomicAdd(&p.y[oi], v);
-                    else p.y[oi] = v;
+            for (int r8 = 0; r8 < 16; r8 += 8) {
+                float dwv[8][NPB];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int o = n0 + (wo * NOB + ob) * 32 + ((r8 + rr) & 3) + 8 * ((r8 + rr) >> 2) + 4 * half;
+                    const float* dw = p.dot_with + (int64_t)(b * p.N + (o < p.N ? o : 0)) * out_plane;
+#pragma unroll
+                    for (int pb = 0; pb < NPB; ++pb) dwv[rr][pb] = dw[valid[pb] ? pix[pb] : 0];
+                }
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = r8 + rr;
+                    const int ol = (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ov = n0 + ol < p.N;
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int pb = 0; pb < NPB; ++pb)
+                        if (ov && valid[pb]) dsum += acc[ob][pb][r] * dwv[rr][pb];
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);  // within each 32-lane half
+                    if (j == 0 && ov) atomicAdd(&red[ol], dsum);
                 }
             }
-            if (EPI == EPI_DOT) {
+        }
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);  // within each 32-lane half
-                if (j == 0 && ov) atomicAdd(&red[ol], dsum);
+        for (int r = 0; r < 16; ++r) {  // pass 2: stores only
+            const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (o >= p.N) continue;
+            float* yp = p.y + (int64_t)(b * p.N + o) * out_plane;
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                if (!valid[pb]) continue;
+                float v = acc[ob][pb][r] * os[r];
+                if (EPI == EPI_ACT) {
+                    v += bs[r] + nz[pb];
+                    v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
+                }
+                if (p.tune_skip & 1) {
+                    if (v == 123456.789f) yp[pix[pb]] = v;  // keeps the epilogue arithmetic alive
+                } else if (p.splits > 1) atomicAdd(&yp[pix[pb]], v);
+                else yp[pix[pb]] = v;
             }
         }
     }
@@ -399,13 +430,15 @@ __global__ __launch_bounds__(256) void upconv_border_kernel(ConvParams p, int gr
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] += red[q][ol][t];
     const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
-    float* yp = p.y + ((int64_t)b * p.N + o) * OH * OW;
+    // phase-planar output [2][2][H+1][W+1]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]
+    const int hp = p.H + 1, wp = p.W + 1;
+    float* yp = p.y + ((int64_t)b * p.N + o) * 4 * hp * wp;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int e = e0 + t;
         if (e >= lim) continue;
-        if (is_row) yp[(int64_t)(OH - 1) * OW + e] = acc[t] * os;
-        else yp[(int64_t)e * OW + OW - 1] = acc[t] * os;
+        const int Y = is_row ? OH - 1 : e, X = is_row ? e : OW - 1;
+        yp[(((Y & 1) * 2 + (X & 1)) * hp + (Y >> 1)) * wp + (X >> 1)] = acc[t] * os;
     }
 }
 
@@ -444,13 +477,14 @@ static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipS
         case 5: launch_cfg<MODE, EPI, 1, 2, 2, 2, KC>(p, grid, lds, s); return true;
         case 6: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
         case 7: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
+        case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC>(p, grid, lds, s); return true;
     }
     return false;
 }
 
 static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},               // 512 threads, 1 workgroup / CU
-                                   {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}};  // 256 threads
-static const int kNumCfg = 8;
+                                   {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4}};  // 256 threads
+static const int kNumCfg = 9;
 
 static int next_pow2(int v) {
     int r = 1;
@@ -514,10 +548,12 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         if (th < 1) continue;
         const int ph = mode == W2E_CONV_SAME ? th + 2 : (up ? th + 1 : 2 * th + 1);
         const int pw = mode == W2E_CONV_SAME ? tw + 2 : (up ? tw + 1 : 2 * tw + 1);
-        const size_t lds_c = up ? sizeof(float) * ((size_t)32 * tn + (size_t)16 * ph * pw)
+        const int nt = 64 * cfgs[c].wo * cfgs[c].wp;
+        // deepest K-chunk of this tile (UP: light phases go 16 deep unless the register budget forbids it)
+        const int kdeep = (up && cfgs[c].nob * cfgs[c].npb < 8 && max_patch_slots(mode, tm, nt) <= 2) ? 16 : kc;
+        const size_t lds_c = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep * ph * pw)
                                 : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw);
         if (lds_c > 64 * 1024) continue;
-        const int nt = 64 * cfgs[c].wo * cfgs[c].wp;
         if (ph * pw > nt * max_patch_slots(mode, tm, nt)) continue;  // register-prefetch slots per thread
         const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
         const double waves_per_simd = nt / 256.0;
@@ -538,6 +574,11 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
             if (best < 0 || cost < best_cost * 0.97) best = c, best_cost = cost, best_splits = sp;
         }
     }
+    if (const char* sk = getenv("W2E_TUNE_SKIP")) p.tune_skip = atoi(sk);
+    if (const char* force = getenv("W2E_TUNE_CFG")) {  // tuning aid (tools/layer_bench.py): "<cfg>[,<splits>]"
+        int fc = -1, fs = 1;
+        if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < ncfg) best = fc, best_splits = fs > 0 ? fs : 1;
+    }
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
     const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * cfg.npb * cfg.wp;
@@ -552,7 +593,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     p.plane = p.ph * p.pw;
     p.pw_magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)p.pw + 1);
     W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
-    const size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)16 * p.plane)
+    const int nt_best = 64 * cfg.wo * cfg.wp;
+    const int kdeep_best = (up && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
+    const size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
                           : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     W2E_REQUIRE(lds <= 64 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
     p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), kc_max) * kc_max);
@@ -561,7 +604,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
     if (p.splits > 1 &&
-        hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * p.out_h * p.out_w, s) != hipSuccess) {
+        hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * (w + 1) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
         return 2;
     }

@@ -18,6 +18,7 @@ struct UpfirdnParams {
     float* y;
     int64_t planes;
     int in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip;
+    int planar;  // 1: x is phase-planar [planes][2][2][(in_h+1)/2][(in_w+1)/2]
     int act;
     const float* out_scale;
     const float* noise;
@@ -42,7 +43,7 @@ constexpr int MAX_TILE_K = 8;    // taps per axis the tile kernel handles (pitch
 // floats so each thread's window rows are 16-B aligned: ds_read_b128), every thread then slides the taps
 // over a register window: 2*(kw+3) LDS floats read per 8 outputs.
 // 4x4 FIR (the generator's blur), up = down = 1: taps in registers, everything unrolled, ACT compile-time.
-template <bool ACT>
+template <bool ACT, bool PLANAR>
 __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;
@@ -59,20 +60,39 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
         const int plane = t / tiles_per_plane;
         const int rem = t - plane * tiles_per_plane;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const float* src = p.x + (int64_t)plane * p.in_h * p.in_w;
+        const int hp = (p.in_h + 1) >> 1, wp = (p.in_w + 1) >> 1;
+        const float* src = p.x + (int64_t)plane * (PLANAR ? 4 * hp * wp : p.in_h * p.in_w);
         const int oy0 = ty * TH, ox0 = tx * TW;
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
         __syncthreads();  // previous iteration's readers are done
+        if (PLANAR) {
+            // x'[Y&1][X&1][Y>>1][X>>1]: walk each tile row as two unit-stride runs (one per column parity) so the
+            // global reads stay coalesced; the interleave happens in the LDS write.
+            constexpr int HALF = (PW + 1) / 2 + 1;  // columns of one parity inside a tile row (upper bound)
 #pragma unroll
-        for (int it = 0; it < (PH * PW + 255) / 256; ++it) {
-            const int i = tid + it * 256;
-            const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * PW;
-            const int iy = iy0 + r, ix = ix0 + c;
-            const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-            // branch-free: load from a clamped (always valid) address, then select
-            const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
-            const float v = src[cy * p.in_w + cx];
-            if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
+            for (int it = 0; it < (PH * 2 * HALF + 255) / 256; ++it) {
+                const int i = tid + it * 256;
+                const int r = i / (2 * HALF), rem = i - r * (2 * HALF);
+                const int par = rem / HALF, k = rem - par * HALF;
+                const int c = ((par - ix0) & 1) + 2 * k;  // tile column with (ix0 + c) & 1 == par
+                const int iy = iy0 + r, ix = ix0 + c;
+                const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? par : (ix >= p.in_w ? ((p.in_w - 1 - par) & ~1) + par : ix);
+                const float v = src[(((cy & 1) * 2 + par) * hp + (cy >> 1)) * wp + (cx >> 1)];
+                if (r < PH && c < PW) tile[r * PITCH + c] = ok ? v : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < (PH * PW + 255) / 256; ++it) {
+                const int i = tid + it * 256;
+                const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * PW;
+                const int iy = iy0 + r, ix = ix0 + c;
+                const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+                // branch-free: load from a clamped (always valid) address, then select
+                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
+                const float v = src[cy * p.in_w + cx];
+                if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
+            }
         }
         __syncthreads();
         float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -217,7 +237,7 @@ __global__ void upfirdn_generic_kernel(UpfirdnParams p, int64_t total) {
 using namespace w2e;
 
 extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, int in_h, int in_w, int out_h,
-                             int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int act,
+                             int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout, int act,
                              const float* out_scale, const float* noise, const float* noise_w, const float* bias,
                              int channels, float slope, float gain, void* stream) {
     W2E_REQUIRE(x && kern && y, "upfirdn2d: null tensor");
@@ -229,7 +249,9 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     W2E_REQUIRE(!act || !bias || channels > 0, "upfirdn2d: bias needs channels");
     const int64_t total = planes * out_h * out_w;
     if (total == 0) return 0;
-    UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip,
+    W2E_REQUIRE(in_layout == 0 || (in_layout == 1 && up == 1 && down == 1 && kh == 4 && kw == 4 && out_w >= 32),
+                "upfirdn2d: the phase-planar input layout is implemented for the 4x4, up=down=1 tile kernel only");
+    UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip, in_layout,
                     act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain};
     hipStream_t s = (hipStream_t)stream;
     if (up == 1 && down == 1 && out_w >= 32 && kh <= MAX_TILE_K && kw <= MAX_TILE_K) {
@@ -241,8 +263,13 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
         const int grid = (int)(n_tiles < 16384 ? n_tiles : 16384);
         const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)pw + 1);
         if (kh == 4 && kw == 4) {
-            if (act) upfirdn_tile4_kernel<true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-            else upfirdn_tile4_kernel<false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+            if (in_layout) {
+                if (act) upfirdn_tile4_kernel<true, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                else upfirdn_tile4_kernel<false, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+            } else {
+                if (act) upfirdn_tile4_kernel<true, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                else upfirdn_tile4_kernel<false, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+            }
         } else {
             upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
         }

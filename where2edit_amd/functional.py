@@ -20,9 +20,11 @@ def _c(t):
 
 
 # ------------------------------------------------------------------------------------------ K2
-def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=None):
-    """One launch of w2e_upfirdn2d.  `act` = (out_scale[planes]|None, noise[HW]|None, noise_w|None, bias[C]|None)."""
-    n, c, h, w = x.shape
+def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=None, planar_hw=None):
+    """One launch of w2e_upfirdn2d.  `act` = (out_scale[planes]|None, noise[HW]|None, noise_w|None, bias[C]|None).
+    planar_hw=(in_h, in_w): x is the phase-planar [N,C,2,2,(in_h+1)/2,(in_w+1)/2] image the UP conv writes."""
+    n, c = x.shape[0], x.shape[1]
+    h, w = planar_hw if planar_hw is not None else (x.shape[2], x.shape[3])
     kh, kw = kernel.shape
     y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32)
     if act is None:
@@ -32,7 +34,7 @@ def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=
         a = (1, ptr(out_scale), ptr(noise), ptr(noise_w), ptr(bias), c, 0.2, SQRT2)
     sp = profiling.span("upfirdn2d", 4.0 * n * c * (h * w + out_h * out_w))  # algorithmic bytes: read x + write y
     call("w2e_upfirdn2d", ptr(x), ptr(kernel), ptr(y), n * c, h, w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0,
-         int(flip), *a, stream_ptr())
+         int(flip), int(planar_hw is not None), *a, stream_ptr())
     if sp is not None:
         sp.end()
     return y
@@ -132,8 +134,10 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     n = wp.shape[2]
     if wp.shape[0] != k:
         raise RuntimeError(f"modconv: packed weight expects {wp.shape[0]} input channels, got {k}")
-    oh, ow = (h, w) if mode != MODE_UP else (2 * h + 1, 2 * w + 1)
-    y = torch.empty((b, n, oh, ow), device=x.device, dtype=torch.float32)
+    if mode == MODE_UP:  # phase-planar T: T[Y][X] = y[Y&1][X&1][Y>>1][X>>1]  (unit-stride stores per output phase)
+        y = torch.empty((b, n, 2, 2, h + 1, w + 1), device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
     dot = torch.zeros((b, n), device=x.device, dtype=torch.float32) if dot_with is not None else None
     noise = noise_w = bias = None
     if act is not None:
@@ -156,6 +160,12 @@ def demod_coefficients(s, wsq, eps=1e-8):
     return d
 
 
+def unplanar(t):
+    """[B,N,2,2,H+1,W+1] phase-planar transposed-conv output -> the plain [B,N,2H+1,2W+1] image."""
+    b, n, _, _, hp, wp = t.shape
+    return t.permute(0, 1, 4, 2, 5, 3).reshape(b, n, 2 * hp, 2 * wp)[:, :, :2 * hp - 1, :2 * wp - 1].contiguous()
+
+
 class _StyledConv(torch.autograd.Function):
     """Fused StyledConv: out = lrelu(d * conv(Wp, s*x) [blur] + nw*noise + bias) * sqrt2 with
     d = rsqrt(s^2 @ wsq^T + eps) (model.py:234-276, 285-290, op/fused_act.py); with fuse_act=False just
@@ -172,8 +182,12 @@ class _StyledConv(torch.autograd.Function):
         act = (noise, noise_w, bias) if fuse_act else None
         if upsample:
             t, _ = _modconv_raw(MODE_UP, x, wp_f, s, d, h, w)
-            out = _upfirdn2d_raw(t, blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
-                                 act=((None,) + act) if fuse_act else None)
+            if w >= 16:   # the tile kernel reads the phase-planar layout directly
+                out = _upfirdn2d_raw(t, blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
+                                     act=((None,) + act) if fuse_act else None, planar_hw=(2 * h + 1, 2 * w + 1))
+            else:         # tiny images: re-interleave (a [B,C,<=17,<=17] copy) and use the generic kernel
+                out = _upfirdn2d_raw(unplanar(t), blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
+                                     act=((None,) + act) if fuse_act else None)
         else:
             out, _ = _modconv_raw(MODE_SAME, x, wp_f, s, d, h, w, act=act)
         ctx.save_for_backward(x, s, d, wsq, noise, noise_w, bias, out, wp_b, blur_kernel)
