@@ -126,3 +126,18 @@ def test_two_rank_data_parallel_step_equals_full_batch_step(tmp_path):
     for n, p in coach.net.mapper.named_parameters():
         assert torch.equal(a[n], b[n]), n                       # replicas identical after the all-reduce
         assert_close(a[n], p.detach(), 2e-4, f"dp2 == single-process full batch: {n}")
+
+
+def test_id_loss_term_on_gpu_matches_cpu_execution():
+    """A9 (config 3): IDLoss runs on stock PyTorch-ROCm ops (MIOpen) -- same module, GPU vs CPU, on generator outputs."""
+    from where2edit_amd.id_loss import IDLoss
+    loss_mod = IDLoss(types.SimpleNamespace(ir_se50_weights=None))
+    loss_mod.facenet.load_state_dict(seeded.irse_fill(loss_mod.facenet.state_dict()), strict=True)
+    coach, _, _ = _coach(_opts())
+    w = seeded.wplus_latents(2, OG.n_latent(SIZE), salt=21).to(DEV)
+    with torch.no_grad():
+        x, x_hat, _ = coach.forward_pair(w)
+        ref, _ = loss_mod(x_hat.cpu(), x.cpu())
+        got, zero = loss_mod.to(DEV)(x_hat, x)
+    assert zero == 0
+    assert abs(float(got) - float(ref)) <= 1e-3 * max(1.0, abs(float(ref)))
