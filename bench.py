@@ -69,6 +69,18 @@ def synthetic_latents(gen, batch, rank):
     return w.unsqueeze(1).repeat(1, gen.n_latent, 1).contiguous()
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the conv kernel from the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of
+    this same command, corrected as MI355X_MICROARCH.md prescribes) -- recorded in profiles/traffic.json by
+    tools/pmc_traffic.py; None when that file is absent."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["modconv_hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(size):
     """The oracle's mapper step (oracle/step.py, a port of coach.py:79-92 on stock CPU torch ops) at batch 1
     on this box's host cores: one full step (2 G forwards + CLIP + backward + Ranger).  Bounded sample."""
@@ -171,7 +183,7 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "w2e::modconv_kernel (fp32 MFMA 32x32x2 implicit-GEMM 3x3 modconv; "
                                "all tile configs, fwd + dgrad)", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                                "launches": calls, "avg_launch_ms": ms / calls, "flop_per_launch": flops / calls,
                                "share_of_step": ms / (1e3 * dt)}
         c2, ms2, by2 = s.get("upfirdn2d", (0, 0.0, 0.0))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes of bench.py (--pmc FETCH_SIZE and --pmc WRITE_SIZE, each with --kernel-trace only)
+into profiles/<tag>_pmc_hbm_traffic.txt and profiles/traffic.json.
+
+    tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag>
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(path, counter):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        key = "w2e::modconv_kernel<*>" if "modconv_kernel" in name else name.split("(")[0][:60]
+        d[key][0] += 1
+        d[key][1] += float(r["Counter_Value"])
+    return d
+
+
+def main():
+    f, w, tag = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
+    lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of",
+             "#   python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing   (batch 4, 1024^2)",
+             "# per-launch averages.  HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950's FETCH_SIZE reads exactly 1/2 on wide",
+             "# (16 B/lane) streaming reads (MI355X_MICROARCH.md, HBM); verified here on torgb_fwd (float4 loads: 2*FETCH = its",
+             "# algorithmic 313 MB/launch).  The conv kernel stages activations with 4 B/lane loads, for which the factor is",
+             "# uncalibrated: its corrected figure is an upper bound, the uncorrected one a lower bound.",
+             "# kernel, launches, FETCH_SIZE KB/launch, WRITE_SIZE KB/launch, HBM MB/launch corrected, uncorrected"]
+    out = {}
+    for k in sorted(f, key=lambda k: -f[k][1]):
+        if k not in w:
+            continue
+        n = f[k][0]
+        fk, wk = f[k][1] / n, w[k][1] / w[k][0]
+        if fk + wk < 1000:
+            continue
+        lines.append(f"{k}, {n}, {fk:.0f}, {wk:.0f}, {(2 * fk + wk) / 1024:.1f}, {(fk + wk) / 1024:.1f}")
+        out[k] = (2 * fk + wk) * 1024
+    txt = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.txt")
+    open(txt, "w").write("\n".join(lines) + "\n")
+    json.dump({"source": os.path.relpath(txt, ROOT), "modconv_hbm_bytes_per_launch": out["w2e::modconv_kernel<*>"]},
+              open(os.path.join(ROOT, "profiles", "traffic.json"), "w"))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,7 @@ struct ConvParams {
     int tiles_x, tiles_y, tiles_n;
     int ph, pw, plane;
     unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
+    int border_wgs, groups_row, groups_col;  // UP: leading workgroups that compute the last row / column
     int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
 };
@@ -114,6 +115,92 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float*
     }
 }
 
+// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the a=2
+// (row) / b=2 (column) taps reach them.  These elements are produced by the FIRST `border_wgs` workgroups of the UP
+// launch itself (same kernel, so they overlap the MFMA workgroups instead of costing a serialized launch).  One block = 8 consecutive border elements of one image x OL output
+// channels; its threads are OL channel lanes (coalesced weight reads) x KG slices of the input channels
+// (the reduction is a chain of dependent-latency loads, so it is split KG ways and unrolled), LDS-reduced.
+template <int OL, int NT>
+__device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, int wg) {
+    constexpr int KG = NT / OL;
+    float (*red)[OL][8] = reinterpret_cast<float (*)[OL][8]>(smem);  // [KG][OL][8] in the kernel's dynamic LDS
+    const int groups_row = p.groups_row, groups_col = p.groups_col;
+    const int OH = 2 * p.H + 1, OW = 2 * p.W + 1;
+    const int groups = groups_row + groups_col;
+    const int n_chunks = (p.N + OL - 1) / OL;
+    const int o_chunk = wg % n_chunks, bg = wg / n_chunks;
+    const int b = bg / groups, g = bg % groups;
+    const bool is_row = g < groups_row;
+    const int e0 = (is_row ? g : g - groups_row) * 8;  // first X (row) or Y (column) of the group
+    const int lim = is_row ? OW : OH - 1;               // the corner belongs to the row
+    const int L = is_row ? p.W : p.H;                   // input extent along the border
+    const int64_t in_plane = (int64_t)p.H * p.W;
+    const int v0 = (e0 >> 1) - 1;                       // input positions v0 .. v0+4 feed 8 outputs
+    const int64_t stride = is_row ? 1 : p.W;
+    const int64_t fixed = is_row ? (int64_t)(p.H - 1) * p.W : (p.W - 1);
+    const int ol = threadIdx.x % OL, kg = threadIdx.x / OL;
+    const int o = o_chunk * OL + ol;
+    const bool ov = o < p.N;
+    // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
+    const int64_t t0 = (is_row ? 6 : 2) * (int64_t)p.N, t1 = (is_row ? 7 : 5) * (int64_t)p.N, t2 = 8 * (int64_t)p.N;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // unconditional loads at clamped positions (masked afterwards) so that the channel loop can be batched:
+    // 4 channels = 36 independent loads in flight per thread instead of one dependent round trip per channel
+    int64_t xoff[5];
+    float msk[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int v = v0 + t;
+        msk[t] = (v >= 0 && v < L) ? 1.f : 0.f;
+        xoff[t] = fixed + (int64_t)(v < 0 ? 0 : (v >= L ? L - 1 : v)) * stride;
+    }
+    const int kper = (((p.K + KG - 1) / KG) + 3) & ~3;
+    const int i_lo = kg * kper, i_hi = (i_lo + kper < p.K) ? i_lo + kper : p.K;
+    const float* xb = p.x + (int64_t)b * p.K * in_plane;
+    const float* wb = p.wp + (ov ? o : 0);
+    for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
+        float xv[4][5], wv[4][3], sv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = (i0 + c < p.K) ? i0 + c : p.K - 1;
+            sv[c] = (i0 + c < i_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f) : 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) xv[c][t] = xb[(int64_t)i * in_plane + xoff[t]];
+            const float* wq = wb + (int64_t)i * 9 * p.N;
+            wv[c][0] = wq[t0], wv[c][1] = wq[t1], wv[c][2] = wq[t2];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) xv[c][t] *= sv[c] * msk[t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
+                acc[2 * t] += wv[c][0] * xv[c][t + 1] + wv[c][2] * xv[c][t];
+                acc[2 * t + 1] += wv[c][1] * xv[c][t + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[kg][ol][t] = acc[t];
+    __syncthreads();
+    if (kg != 0 || !ov) return;
+#pragma unroll
+    for (int q = 1; q < KG; ++q)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] += red[q][ol][t];
+    const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
+    // phase-planar output [2][2][H+1][W+1]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]
+    const int hp = p.H + 1, wp = p.W + 1;
+    float* yp = p.y + ((int64_t)b * p.N + o) * 4 * hp * wp;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int e = e0 + t;
+        if (e >= lim) continue;
+        const int Y = is_row ? OH - 1 : e, X = is_row ? e : OW - 1;
+        yp[(((Y & 1) * 2 + (X & 1)) * hp + (Y >> 1)) * wp + (X >> 1)] = acc[t] * os;
+    }
+}
+
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
 __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
     constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
@@ -129,8 +216,16 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int wo = wave / WP, wpx = wave % WP;
 
     int bid = blockIdx.x;
+    if (MODE == W2E_CONV_UP) {
+        if (bid < p.border_wgs) {  // uniform per workgroup
+            if (p.N >= 64) upconv_border<64, NT>(p, smem, bid);
+            else upconv_border<32, NT>(p, smem, bid);
+            return;
+        }
+        bid -= p.border_wgs;
+    }
     // UP: phase-major grid, phase 0 (4 taps) first so the light phases fill the tail; (py,px) = (phase>>1, phase&1)
-    const int per_phase = gridDim.x >> 2;
+    const int per_phase = (gridDim.x - p.border_wgs) >> 2;
     const int phase = (MODE == W2E_CONV_UP) ? bid / per_phase : 0;
     if (MODE == W2E_CONV_UP) bid -= phase * per_phase;
     const int ks = bid % p.splits;
@@ -360,88 +455,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     }
 }
 
-// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the a=2
-// (row) / b=2 (column) taps reach them.  One block = 8 consecutive border elements of one image x OL output
-// channels; its 256 threads are OL channel lanes (coalesced weight reads) x KG slices of the input channels
-// (the reduction is a chain of dependent-latency loads, so it is split KG ways and unrolled), LDS-reduced.
-template <int OL>
-__global__ __launch_bounds__(256) void upconv_border_kernel(ConvParams p, int groups_row, int groups_col) {
-    constexpr int KG = 256 / OL;
-    __shared__ float red[KG][OL][8];
-    const int OH = 2 * p.H + 1, OW = 2 * p.W + 1;
-    const int groups = groups_row + groups_col;
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
-    const bool is_row = g < groups_row;
-    const int e0 = (is_row ? g : g - groups_row) * 8;  // first X (row) or Y (column) of the group
-    const int lim = is_row ? OW : OH - 1;               // the corner belongs to the row
-    const int L = is_row ? p.W : p.H;                   // input extent along the border
-    const int64_t in_plane = (int64_t)p.H * p.W;
-    const int v0 = (e0 >> 1) - 1;                       // input positions v0 .. v0+4 feed 8 outputs
-    const int64_t stride = is_row ? 1 : p.W;
-    const int64_t fixed = is_row ? (int64_t)(p.H - 1) * p.W : (p.W - 1);
-    const int ol = threadIdx.x % OL, kg = threadIdx.x / OL;
-    const int o = blockIdx.y * OL + ol;
-    const bool ov = o < p.N;
-    // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
-    const int64_t t0 = (is_row ? 6 : 2) * (int64_t)p.N, t1 = (is_row ? 7 : 5) * (int64_t)p.N, t2 = 8 * (int64_t)p.N;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // unconditional loads at clamped positions (masked afterwards) so that the channel loop can be batched:
-    // 4 channels = 36 independent loads in flight per thread instead of one dependent round trip per channel
-    int64_t xoff[5];
-    float msk[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int v = v0 + t;
-        msk[t] = (v >= 0 && v < L) ? 1.f : 0.f;
-        xoff[t] = fixed + (int64_t)(v < 0 ? 0 : (v >= L ? L - 1 : v)) * stride;
-    }
-    const int kper = (((p.K + KG - 1) / KG) + 3) & ~3;
-    const int i_lo = kg * kper, i_hi = (i_lo + kper < p.K) ? i_lo + kper : p.K;
-    const float* xb = p.x + (int64_t)b * p.K * in_plane;
-    const float* wb = p.wp + (ov ? o : 0);
-    for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
-        float xv[4][5], wv[4][3], sv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = (i0 + c < p.K) ? i0 + c : p.K - 1;
-            sv[c] = (i0 + c < i_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f) : 0.f;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) xv[c][t] = xb[(int64_t)i * in_plane + xoff[t]];
-            const float* wq = wb + (int64_t)i * 9 * p.N;
-            wv[c][0] = wq[t0], wv[c][1] = wq[t1], wv[c][2] = wq[t2];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int t = 0; t < 5; ++t) xv[c][t] *= sv[c] * msk[t];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
-                acc[2 * t] += wv[c][0] * xv[c][t + 1] + wv[c][2] * xv[c][t];
-                acc[2 * t + 1] += wv[c][1] * xv[c][t + 1];
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) red[kg][ol][t] = acc[t];
-    __syncthreads();
-    if (kg != 0 || !ov) return;
-#pragma unroll
-    for (int q = 1; q < KG; ++q)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] += red[q][ol][t];
-    const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
-    // phase-planar output [2][2][H+1][W+1]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]
-    const int hp = p.H + 1, wp = p.W + 1;
-    float* yp = p.y + ((int64_t)b * p.N + o) * 4 * hp * wp;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int e = e0 + t;
-        if (e >= lim) continue;
-        const int Y = is_row ? OH - 1 : e, X = is_row ? e : OW - 1;
-        yp[(((Y & 1) * 2 + (X & 1)) * hp + (Y >> 1)) * wp + (X >> 1)] = acc[t] * os;
-    }
-}
-
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, float scale,
                                  int transpose, int flip) {
     const int64_t total = (int64_t)cout * cin * 9;
@@ -595,12 +608,17 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
     const int nt_best = 64 * cfg.wo * cfg.wp;
     const int kdeep_best = (up && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
-    const size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
-                          : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
+    size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
+                    : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
+    if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
     W2E_REQUIRE(lds <= 64 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
     p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), kc_max) * kc_max);
     p.splits = (int)ceil_div(k_ch, p.k_per);
-    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * (up ? 4 : 1) * p.splits;
+    if (up) {
+        p.groups_row = (int)ceil_div(2 * w + 1, 8), p.groups_col = (int)ceil_div(2 * h, 8);
+        p.border_wgs = batch * (p.groups_row + p.groups_col) * (int)ceil_div(n_ch, n_ch >= 64 ? 64 : 32);
+    }
+    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * (up ? 4 : 1) * p.splits + p.border_wgs;
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
     if (p.splits > 1 &&
@@ -624,17 +642,6 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     if (act && p.splits > 1) {  // the activation needs the complete sum: one in-place elementwise pass
         const int rc = w2e_bias_act_fwd(y, bias, noise, noise_w, y, batch, n_ch, (int64_t)h * w, 0.2f, 1.4142135623730951f, stream);
         if (rc != 0) return rc;
-    }
-    if (up) {
-        const int groups_row = (int)ceil_div(2 * w + 1, 8), groups_col = (int)ceil_div(2 * h, 8);
-        if (n_ch >= 64) {
-            dim3 grid((unsigned)(batch * (groups_row + groups_col)), (unsigned)ceil_div(n_ch, 64));
-            upconv_border_kernel<64><<<grid, 256, 0, s>>>(p, groups_row, groups_col);
-        } else {
-            dim3 grid((unsigned)(batch * (groups_row + groups_col)), (unsigned)ceil_div(n_ch, 32));
-            upconv_border_kernel<32><<<grid, 256, 0, s>>>(p, groups_row, groups_col);
-        }
-        W2E_LAUNCH_CHECK("modconv3x3 border");
     }
     return 0;
 }
