@@ -342,3 +342,33 @@ def test_cpu_tensor_is_refused():
     from where2edit_amd.op import upfirdn2d
     with pytest.raises(RuntimeError, match="GPU only"):
         upfirdn2d(torch.randn(1, 1, 8, 8), torch.ones(2, 2))
+
+
+def test_empty_batch_passes_through():
+    """Batch 0 (e.g. a rank whose shard is empty) behaves like the torch reference: empty outputs, no launch."""
+    from where2edit_amd.functional import clip_preprocess, mask_blend
+    from where2edit_amd.op import fused_leaky_relu, upfirdn2d
+    from where2edit_amd.stylegan2 import StyledConv, ToRGB
+    k = cu(O.make_kernel((1, 3, 3, 1)))
+    assert upfirdn2d(torch.empty(0, 3, 8, 8, device=DEV), k, up=2, pad=(2, 1)).shape == (0, 3, 16, 16)
+    assert fused_leaky_relu(torch.empty(0, 4, device=DEV), torch.zeros(4, device=DEV)).shape == (0, 4)
+    m = StyledConv(8, 8, 3, 512, upsample=True).to(DEV)
+    y, s = m(torch.empty(0, 8, 4, 4, device=DEV), torch.empty(0, 512, device=DEV), noise=torch.zeros(1, 1, 8, 8, device=DEV))
+    assert y.shape == (0, 8, 8, 8) and s.shape == (0, 1, 8, 1, 1)
+    r = ToRGB(8, 512, upsample=False).to(DEV)
+    assert r(torch.empty(0, 8, 4, 4, device=DEV), torch.empty(0, 512, device=DEV))[0].shape == (0, 3, 4, 4)
+    assert clip_preprocess(torch.empty(0, 3, 64, 64, device=DEV)).shape == (0, 3, 224, 224)
+    assert mask_blend(torch.empty(0, 2, 4, 4, device=DEV), torch.empty(0, 2, 4, 4, device=DEV),
+                      torch.empty(0, 1, 2, 2, device=DEV)).shape == (0, 2, 4, 4)
+
+
+def test_argument_errors_surface_as_exceptions():
+    """Error convention of the boundary: bad arguments -> non-zero status -> RuntimeError with the library's message."""
+    from where2edit_amd.functional import _upfirdn2d_raw, clip_preprocess
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        clip_preprocess(torch.zeros(1, 3, 48, 48, device=DEV))
+    with pytest.raises(RuntimeError, match="unsupported"):
+        _upfirdn2d_raw(torch.zeros(1, 1, 40, 40, device=DEV), torch.ones(17, 17, device=DEV), 24, 24, 1, 1, 0, 0, True)
+    with pytest.raises(RuntimeError, match="fp32"):
+        from where2edit_amd.op import upfirdn2d
+        upfirdn2d(torch.zeros(1, 1, 8, 8, device=DEV, dtype=torch.float16), torch.ones(2, 2, device=DEV))

@@ -74,10 +74,13 @@ def ptr(t):
         raise RuntimeError(f"where2edit_amd kernels are fp32 (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError("internal: non-contiguous tensor passed to a kernel")
-    return ctypes.c_void_p(t.data_ptr())
+    # an empty tensor has no storage: hand the ABI a non-NULL dummy address (it is never dereferenced -- every entry
+    # point returns before launching when a dimension is 0) so that "NULL" keeps meaning "argument absent"
+    return ctypes.c_void_p(t.data_ptr() if t.numel() else 16)
 
 
 def call(name, *args):
+    """Invoke an entry point; a non-zero status becomes RuntimeError(w2e_last_error())."""
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
