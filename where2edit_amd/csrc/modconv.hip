@@ -190,7 +190,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
         for (int t = 0; t < 8; ++t) acc[t] += red[q][ol][t];
     const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
     // phase-planar output [2][2][H+1][W+1]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]
-    const int hp = p.H + 1, wp = p.W + 1;
+    const int hp = p.H + 1, wp = (p.W + 4) & ~3;  // 16-B aligned plane rows
     float* yp = p.y + ((int64_t)b * p.N + o) * 4 * hp * wp;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -389,11 +389,11 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
         // UP writes its phase plane of the phase-planar image [4][H+1][W+1]: unit-stride rows
-        if (MODE == W2E_CONV_UP) pix[pb] = (phase * (p.H + 1) + gy[pb]) * (p.W + 1) + gx[pb];
+        if (MODE == W2E_CONV_UP) pix[pb] = (phase * (p.H + 1) + gy[pb]) * ((p.W + 4) & ~3) + gx[pb];
         else pix[pb] = gy[pb] * p.out_w + gx[pb];
         nz[pb] = (EPI == EPI_ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
     }
-    const int out_plane = (MODE == W2E_CONV_UP) ? 4 * (p.H + 1) * (p.W + 1) : p.out_h * p.out_w;
+    const int out_plane = (MODE == W2E_CONV_UP) ? 4 * (p.H + 1) * ((p.W + 4) & ~3) : p.out_h * p.out_w;
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         float os[16], bs[16];
@@ -622,7 +622,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
     if (p.splits > 1 &&
-        hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * (w + 1) : p.out_h * p.out_w), s) != hipSuccess) {
+        hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
         return 2;
     }

@@ -6,6 +6,8 @@
 //     (16+kh-1) x (64+kw-1) input tile staged once in LDS, 4 outputs per thread, float4 stores,
 //     optional fused demod/noise/bias/LeakyReLU epilogue so the activation is written once.
 //   * upfirdn_generic_kernel -- any up/down/pad/flip (RGB skip up-sampling, Downsample, adjoints).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace w2e {
@@ -18,6 +20,7 @@ struct UpfirdnParams {
     float* y;
     int64_t planes;
     int in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip;
+    int tune;    // tuning aid (W2E_TUNE_BLUR): 1 = no global loads, 2 = no FIR arithmetic, 4 = no stores
     int planar;  // 1: x is phase-planar [planes][2][2][(in_h+1)/2][(in_w+1)/2]
     int act;
     const float* out_scale;
@@ -43,7 +46,7 @@ constexpr int MAX_TILE_K = 8;    // taps per axis the tile kernel handles (pitch
 // floats so each thread's window rows are 16-B aligned: ds_read_b128), every thread then slides the taps
 // over a register window: 2*(kw+3) LDS floats read per 8 outputs.
 // 4x4 FIR (the generator's blur), up = down = 1: taps in registers, everything unrolled, ACT compile-time.
-template <bool ACT, bool PLANAR>
+template <bool ACT, bool PLANAR, bool VEC>
 __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;
@@ -61,25 +64,54 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
         const int rem = t - plane * tiles_per_plane;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
         const int hp = (p.in_h + 1) >> 1, wp = (p.in_w + 1) >> 1;
-        const float* src = p.x + (int64_t)plane * (PLANAR ? 4 * hp * wp : p.in_h * p.in_w);
+        const float* src = p.x + (int64_t)plane * (PLANAR ? 4 * hp * ((wp + 3) & ~3) : p.in_h * p.in_w);
         const int oy0 = ty * TH, ox0 = tx * TW;
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
         __syncthreads();  // previous iteration's readers are done
         if (PLANAR) {
-            // x'[Y&1][X&1][Y>>1][X>>1]: walk each tile row as two unit-stride runs (one per column parity) so the
-            // global reads stay coalesced; the interleave happens in the LDS write.
-            constexpr int HALF = (PW + 1) / 2 + 1;  // columns of one parity inside a tile row (upper bound)
+            // x'[Y&1][X&1][Y>>1][X>>1] with a 16-B aligned row pitch wpp: each tile row is two unit-stride runs (one
+            // per column parity), read as aligned float4s; the interleave happens in the LDS write.
+            const int wpp = (wp + 3) & ~3;
+            constexpr int NQ = ((PW + 1) / 2 + 1 + 3) / 4 + 1;  // float4s covering one parity run of a tile row
 #pragma unroll
-            for (int it = 0; it < (PH * 2 * HALF + 255) / 256; ++it) {
+            for (int it = 0; it < (PH * 2 * NQ + 255) / 256; ++it) {
                 const int i = tid + it * 256;
-                const int r = i / (2 * HALF), rem = i - r * (2 * HALF);
-                const int par = rem / HALF, k = rem - par * HALF;
-                const int c = ((par - ix0) & 1) + 2 * k;  // tile column with (ix0 + c) & 1 == par
-                const int iy = iy0 + r, ix = ix0 + c;
-                const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? par : (ix >= p.in_w ? ((p.in_w - 1 - par) & ~1) + par : ix);
-                const float v = src[(((cy & 1) * 2 + par) * hp + (cy >> 1)) * wp + (cx >> 1)];
-                if (r < PH && c < PW) tile[r * PITCH + c] = ok ? v : 0.f;
+                const int r = i / (2 * NQ), rem = i - r * (2 * NQ);
+                const int par = rem / NQ, q = rem - par * NQ;
+                const int iy = iy0 + r;
+                const int v_lo = (ix0 - par + 1) >> 1;            // first v with 2v+par >= ix0 (arithmetic shift: floor)
+                const int v4 = (v_lo & ~3) + 4 * q;               // aligned chunk start
+                const bool row_ok = r < PH && iy >= 0 && iy < p.in_h;
+                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy);
+                const float* rowp = src + (((cy & 1) * 2 + par) * hp + (cy >> 1)) * wpp;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(p.tune & 1) && row_ok && v4 >= 0 && v4 + 3 < wpp) v = *reinterpret_cast<const float4*>(rowp + v4);
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ix = 2 * (v4 + k) + par, c = ix - ix0;
+                    if (r < PH && c >= 0 && c < PW) tile[r * PITCH + c] = (row_ok && ix >= 0 && ix < p.in_w) ? e[k] : 0.f;
+                }
+            }
+        } else if (VEC) {
+            // rows of the plain image are 16-B aligned (in_w % 4 == 0): aligned float4 reads of the covering span
+            constexpr int NQ = (PW + 3) / 4 + 1;
+            const int xa = ix0 & ~3;
+#pragma unroll
+            for (int it = 0; it < (PH * NQ + 255) / 256; ++it) {
+                const int i = tid + it * 256;
+                const int r = i / NQ, q = i - r * NQ;
+                const int iy = iy0 + r, x4 = xa + 4 * q;
+                const bool row_ok = r < PH && iy >= 0 && iy < p.in_h;
+                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(p.tune & 1) && row_ok && x4 >= 0 && x4 + 3 < p.in_w) v = *reinterpret_cast<const float4*>(src + cy * p.in_w + x4);
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = x4 + k - ix0;
+                    if (r < PH && c >= 0 && c < PW) tile[r * PITCH + c] = e[k];  // out-of-image chunks stay 0
+                }
             }
         } else {
 #pragma unroll
@@ -90,14 +122,14 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
                 const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
                 // branch-free: load from a clamped (always valid) address, then select
                 const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
-                const float v = src[cy * p.in_w + cx];
+                const float v = (p.tune & 1) ? 1.f : src[cy * p.in_w + cx];
                 if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
             }
         }
         __syncthreads();
         float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {  // input row ly+r feeds output row 0 with ky=r and output row 1 with ky=r-1
+        for (int r = 0; r < ((p.tune & 2) ? 1 : 5); ++r) {  // input row ly+r feeds output row 0 with ky=r and output row 1 with ky=r-1
             const float4 a = *reinterpret_cast<const float4*>(tile + (ly + r) * PITCH + lx);
             const float4 b = *reinterpret_cast<const float4*>(tile + (ly + r) * PITCH + lx + 4);
             const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -132,6 +164,7 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
                 v[j] = e;
             }
             float* dst = p.y + ((int64_t)plane * p.out_h + oy) * p.out_w + ox;
+            if ((p.tune & 4) && v[0] != 123456.75f) continue;
             if (ox + 3 < p.out_w && (p.out_w & 3) == 0) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -251,7 +284,8 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     if (total == 0) return 0;
     W2E_REQUIRE(in_layout == 0 || (in_layout == 1 && up == 1 && down == 1 && kh == 4 && kw == 4 && out_w >= 32),
                 "upfirdn2d: the phase-planar input layout is implemented for the 4x4, up=down=1 tile kernel only");
-    UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip, in_layout,
+    static const int tune = getenv("W2E_TUNE_BLUR") ? atoi(getenv("W2E_TUNE_BLUR")) : 0;
+    UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip, tune, in_layout,
                     act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain};
     hipStream_t s = (hipStream_t)stream;
     if (up == 1 && down == 1 && out_w >= 32 && kh <= MAX_TILE_K && kw <= MAX_TILE_K) {
@@ -263,12 +297,16 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
         const int grid = (int)(n_tiles < 16384 ? n_tiles : 16384);
         const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)pw + 1);
         if (kh == 4 && kw == 4) {
+            const bool vec = !in_layout && (in_w & 3) == 0 && ((uintptr_t)x & 15) == 0;
             if (in_layout) {
-                if (act) upfirdn_tile4_kernel<true, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-                else upfirdn_tile4_kernel<false, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                if (act) upfirdn_tile4_kernel<true, true, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                else upfirdn_tile4_kernel<false, true, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+            } else if (vec) {
+                if (act) upfirdn_tile4_kernel<true, false, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                else upfirdn_tile4_kernel<false, false, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
             } else {
-                if (act) upfirdn_tile4_kernel<true, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-                else upfirdn_tile4_kernel<false, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                if (act) upfirdn_tile4_kernel<true, false, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                else upfirdn_tile4_kernel<false, false, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
             }
         } else {
             upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);

@@ -135,7 +135,7 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     if wp.shape[0] != k:
         raise RuntimeError(f"modconv: packed weight expects {wp.shape[0]} input channels, got {k}")
     if mode == MODE_UP:  # phase-planar T: T[Y][X] = y[Y&1][X&1][Y>>1][X>>1]  (unit-stride stores per output phase)
-        y = torch.empty((b, n, 2, 2, h + 1, w + 1), device=x.device, dtype=torch.float32)
+        y = torch.empty((b, n, 2, 2, h + 1, (w + 4) & ~3), device=x.device, dtype=torch.float32)  # 16-B aligned rows
     else:
         y = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
     dot = torch.zeros((b, n), device=x.device, dtype=torch.float32) if dot_with is not None else None
@@ -160,10 +160,12 @@ def demod_coefficients(s, wsq, eps=1e-8):
     return d
 
 
-def unplanar(t):
-    """[B,N,2,2,H+1,W+1] phase-planar transposed-conv output -> the plain [B,N,2H+1,2W+1] image."""
-    b, n, _, _, hp, wp = t.shape
-    return t.permute(0, 1, 4, 2, 5, 3).reshape(b, n, 2 * hp, 2 * wp)[:, :, :2 * hp - 1, :2 * wp - 1].contiguous()
+def unplanar(t, in_w):
+    """[B,N,2,2,H+1,WP] phase-planar transposed-conv output (WP = W+1 padded to a multiple of 4) -> the plain
+    [B,N,2H+1,2W+1] image."""
+    b, n, _, _, hp, wpp = t.shape
+    w = in_w
+    return t.permute(0, 1, 4, 2, 5, 3).reshape(b, n, 2 * hp, 2 * wpp)[:, :, :2 * hp - 1, :2 * w + 1].contiguous()
 
 
 class _StyledConv(torch.autograd.Function):
@@ -186,7 +188,7 @@ class _StyledConv(torch.autograd.Function):
                 out = _upfirdn2d_raw(t, blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
                                      act=((None,) + act) if fuse_act else None, planar_hw=(2 * h + 1, 2 * w + 1))
             else:         # tiny images: re-interleave (a [B,C,<=17,<=17] copy) and use the generic kernel
-                out = _upfirdn2d_raw(unplanar(t), blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
+                out = _upfirdn2d_raw(unplanar(t, w), blur_kernel, 2 * h, 2 * w, 1, 1, 1, 1, True,
                                      act=((None,) + act) if fuse_act else None)
         else:
             out, _ = _modconv_raw(MODE_SAME, x, wp_f, s, d, h, w, act=act)
