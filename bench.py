@@ -161,6 +161,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     loss = float(last["loss"])
     if not (loss == loss):
@@ -198,6 +200,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
