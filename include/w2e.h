@@ -113,6 +113,12 @@ int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx,
 int w2e_clip_preproc_fwd(const float* img, float* out, int64_t planes, int size, void* stream);
 int w2e_clip_preproc_bwd(const float* gout, float* gimg, int64_t planes, int size, void* stream);
 
+/* ---- K5b  ArcFace (IDLoss) preprocessing  (criteria/id_loss.py:13-14,19-23) -----------------
+ * AdaptiveAvgPool2d(256) -> crop [35:223, 32:220] -> AdaptiveAvgPool2d(112) in one pass:
+ * [planes,size,size] -> [planes,112,112], size a multiple of 256.  bwd is the exact adjoint. */
+int w2e_id_preproc_fwd(const float* img, float* out, int64_t planes, int size, void* stream);
+int w2e_id_preproc_bwd(const float* gout, float* gimg, int64_t planes, int size, void* stream);
+
 /* ---- K6  region-attention blend  (attention/attention_model.py:548-549 and siblings) --------
  * m = nearest-resize(mask[B,1,ms,ms]) to [h,w];  out = m*a + (1-m)*b, a,b [B,C,h,w]. */
 int w2e_mask_blend_fwd(const float* a, const float* b, const float* mask, float* out, int batch, int channels,

@@ -372,3 +372,19 @@ def test_argument_errors_surface_as_exceptions():
     with pytest.raises(RuntimeError, match="fp32"):
         from where2edit_amd.op import upfirdn2d
         upfirdn2d(torch.zeros(1, 1, 8, 8, device=DEV, dtype=torch.float16), torch.ones(2, 2, device=DEV))
+
+
+@pytest.mark.parametrize("size,key,gkey,b", [(1024, "preproc.id", "id1024.y", 2), (256, "preproc.id256", "id256.y", 1)])
+def test_id_preprocess_golden_and_adjoint(size, key, gkey, b):
+    """K5b: pool(256) -> crop -> pool(112) of criteria/id_loss.py:19-23 in one kernel, against the reference chain."""
+    from where2edit_amd.functional import id_preprocess
+    g = golden("preproc")
+    img = seeded.tensor(key, (b, 3, size, size))
+    ig = cu(img).requires_grad_(True)
+    y = id_preprocess(ig)
+    assert_close(y, g[gkey], 1e-5)
+    gy = seeded.tensor("idpre.gy", y.shape)
+    (gx,) = torch.autograd.grad(y, ig, cu(gy))
+    io = img.clone().requires_grad_(True)
+    (go,) = torch.autograd.grad(O.id_preprocess(io), io, gy)
+    assert_close(gx, go, 1e-5, "adjoint")

@@ -243,6 +243,56 @@ __global__ void clip_preproc_bwd_kernel(const float* __restrict__ gout, float* _
     }
 }
 
+// ------------------------------------------------------------------------------------- K5b
+// IDLoss front end (criteria/id_loss.py:19-23): AdaptiveAvgPool(256) [exact k x k mean, k = size/256] -> crop
+// [35:223, 32:220] -> AdaptiveAvgPool(112) on 188 x 188 (windows [floor(i*188/112), ceil((i+1)*188/112)), 2-3 wide).
+__device__ __forceinline__ int apool_lo(int i) { return (i * 188) / 112; }
+__device__ __forceinline__ int apool_hi(int i) { return ((i + 1) * 188 + 111) / 112; }
+
+__global__ void id_preproc_fwd_kernel(const float* __restrict__ img, float* __restrict__ out, int64_t total, int size, int k) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const float inv_k2 = 1.f / (float)(k * k);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int X = (int)(e % 112), Y = (int)((e / 112) % 112);
+        const float* src = img + (e / (112 * 112)) * (int64_t)size * size;
+        const int r0 = apool_lo(Y), r1 = apool_hi(Y), c0 = apool_lo(X), c1 = apool_hi(X);
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r)
+            for (int c = c0; c < c1; ++c) {
+                const float* blk = src + (int64_t)(35 + r) * k * size + (32 + c) * k;
+                float s = 0.f;
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b < k; ++b) s += blk[a * size + b];
+                acc += s * inv_k2;
+            }
+        out[e] = acc / (float)((r1 - r0) * (c1 - c0));
+    }
+}
+
+__global__ void id_preproc_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gimg, int64_t total, int size, int k) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const float inv_k2 = 1.f / (float)(k * k);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int x = (int)(e % size), y = (int)((e / size) % size);
+        const float* g = gout + (e / ((int64_t)size * size)) * 112 * 112;
+        const int r = y / k - 35, c = x / k - 32;
+        float acc = 0.f;
+        if (r >= 0 && r < 188 && c >= 0 && c < 188) {
+            // output windows that contain pooled row r / column c: at most two, around r*112/188
+            const int Yc = (r * 112) / 188, Xc = (c * 112) / 188;
+            for (int Y = Yc - 1; Y <= Yc + 1; ++Y) {
+                if (Y < 0 || Y >= 112 || r < apool_lo(Y) || r >= apool_hi(Y)) continue;
+                const float wy = 1.f / (float)(apool_hi(Y) - apool_lo(Y));
+                for (int X = Xc - 1; X <= Xc + 1; ++X) {
+                    if (X < 0 || X >= 112 || c < apool_lo(X) || c >= apool_hi(X)) continue;
+                    acc += wy / (float)(apool_hi(X) - apool_lo(X)) * g[Y * 112 + X];
+                }
+            }
+        }
+        gimg[e] = acc * inv_k2;
+    }
+}
+
 // ------------------------------------------------------------------------------------- demodulation
 // d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps)   (model.py:241-243 with wsq = sum_k (scale*W)^2).
 // One wave per (b,o).
@@ -426,6 +476,26 @@ int w2e_demod_bwd(const float* sums, const float* dz, const float* noise_w, cons
     dim3 grid((unsigned)ceil_div(cin, 256), (unsigned)batch);
     demod_bwd_kernel<<<grid, 256, sizeof(float) * cout, (hipStream_t)stream>>>(sums, dz, noise_w, bias, d, s, wsq, gs, gd, cin, cout);
     W2E_LAUNCH_CHECK("demod_bwd");
+    return 0;
+}
+
+int w2e_id_preproc_fwd(const float* img, float* out, int64_t planes, int size, void* stream) {
+    W2E_REQUIRE(img && out, "id_preproc_fwd: null tensor");
+    W2E_REQUIRE(size >= 256 && size % 256 == 0, "id_preproc_fwd: size %d must be a positive multiple of 256", size);
+    const int64_t total = planes * 112 * 112;
+    if (total <= 0) return 0;
+    id_preproc_fwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, total, size, size / 256);
+    W2E_LAUNCH_CHECK("id_preproc_fwd");
+    return 0;
+}
+
+int w2e_id_preproc_bwd(const float* gout, float* gimg, int64_t planes, int size, void* stream) {
+    W2E_REQUIRE(gout && gimg, "id_preproc_bwd: null tensor");
+    W2E_REQUIRE(size >= 256 && size % 256 == 0, "id_preproc_bwd: size %d must be a positive multiple of 256", size);
+    const int64_t total = planes * (int64_t)size * size;
+    if (total <= 0) return 0;
+    id_preproc_bwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gout, gimg, total, size, size / 256);
+    W2E_LAUNCH_CHECK("id_preproc_bwd");
     return 0;
 }
 

@@ -1,6 +1,8 @@
 // CLIP ViT-B/32 image-encoder kernels for gfx950 (include/w2e_vit.h): fp32-MFMA GEMM with fused
 // bias / residual / QuickGELU prologue / QuickGELU' epilogue, LayerNorm fwd+bwd, and the 50-token
 // attention core fwd+bwd (one workgroup per (batch, head), everything in LDS).
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/w2e_vit.h"
 
@@ -323,7 +325,9 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     const int64_t tiles = ceil_div(n, GBN) * ceil_div(m, GBM);
     int splits = 1;
     if (!gelu_grad_aux && ldc == n) {
-        while (tiles * splits < 256 && splits < 8 && k / (splits * 2) >= 256) splits *= 2;
+        static const int tune_t = getenv("W2E_TUNE_GEMM_T") ? atoi(getenv("W2E_TUNE_GEMM_T")) : 256;
+        static const int tune_k = getenv("W2E_TUNE_GEMM_K") ? atoi(getenv("W2E_TUNE_GEMM_K")) : 256;
+        while (tiles * splits < tune_t && splits < 16 && k / (splits * 2) >= tune_k) splits *= 2;
     }
     const int k_per = (int)(ceil_div(ceil_div(k, splits), GBK) * GBK);
     splits = (int)ceil_div(k, k_per);

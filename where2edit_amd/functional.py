@@ -310,6 +310,30 @@ def clip_preprocess(img):
     return _ClipPreproc.apply(img)
 
 
+class _IdPreproc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img):
+        img = _c(img)
+        n, c, h, w = img.shape
+        out = torch.empty((n, c, 112, 112), device=img.device, dtype=torch.float32)
+        call("w2e_id_preproc_fwd", ptr(img), ptr(out), n * c, h, stream_ptr())
+        ctx.shape = img.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        n, c, h, w = ctx.shape
+        gimg = torch.empty(ctx.shape, device=gout.device, dtype=torch.float32)
+        call("w2e_id_preproc_bwd", ptr(_c(gout)), ptr(gimg), n * c, h, stream_ptr())
+        return gimg
+
+
+def id_preprocess(img):
+    """face_pool(pool(img)[:, :, 35:223, 32:220]) of criteria/id_loss.py:19-23 in one pass (square, size % 256 == 0)."""
+    return _IdPreproc.apply(img)
+
+
 # ------------------------------------------------------------------------------------------ K6
 class _MaskBlend(torch.autograd.Function):
     @staticmethod

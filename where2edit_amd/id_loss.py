@@ -114,6 +114,9 @@ class IDLoss(nn.Module):
         self.opts = opts
 
     def extract_feats(self, x):
+        if x.is_cuda and x.shape[2] == x.shape[3] and x.shape[2] % 256 == 0 and x.dtype == torch.float32:
+            from . import functional as K  # fused pool -> crop -> pool (K5b); other sizes / CPU: the literal chain below
+            return self.facenet(K.id_preprocess(x))
         if x.shape[2] != 256:
             x = self.pool(x)
         x = x[:, :, 35:223, 32:220]  # crop interesting region (id_loss.py:22)
