@@ -68,9 +68,12 @@ int w2e_bias_act_bwd_reduce(const float* gy, const float* y, const float* noise,
  * with one packed weight tensor shared by the batch.  Forward: in_scale = s, out_scale = demod.
  * Input-gradient: the same kernel on the flipped/transposed pack with in_scale = demod, out_scale = s.
  *
- * w2e_conv_pack: weight [cout,cin,3,3] -> wp [K][9][N] (N contiguous), multiplied by `scale`:
+ * w2e_conv_pack: weight [cout,cin,3,3] -> wp [ceil(K/8)][9][2][N][4] floats, multiplied by `scale`:
+ *   wp[kc][tap][h][n][c] = scale * W(k = 8*kc + 2*c + h, tap, n), zero for k >= K  -- the float4 of (kc, tap, h, n) is what
+ *   lane-half h of the MFMA wave needs for the 4 channel pairs of chunk kc, so the kernel stages and reads it as one 16-B word;
  *   transpose=0: K=cin, N=cout (forward);  transpose=1: K=cout, N=cin (input gradient);
- *   flip=1 reverses the 9 taps (stride-1 input gradient); flip=0 keeps them. */
+ *   flip=1 reverses the 9 taps (stride-1 input gradient); flip=0 keeps them.
+ *   wp must hold ceil(K/8)*288*N floats. */
 int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, float scale, int transpose, int flip,
                   void* stream);
 

@@ -7,8 +7,10 @@
 // [B,Cout,Cin,3,3] weight per call).
 //
 // GEMM view per workgroup: D[o, px] += A[o, k] * B[k, px], k = (ci, tap).
-//   A = packed weights  wp[k][o]  (o contiguous)        -> LDS ws[KC*9][TN]
-//   B = activation patch with halo, pre-multiplied by in_scale -> LDS xs[KC][PH*PW]
+//   A = packed weights, global [K/8][9][2][N][4] (w2e_conv_pack) -> LDS ws[tap][h][TN] of float4: the float4 of
+//       (tap, h, o) holds the chunk's channels 2c+h, c = 0..3, i.e. the A operand of 4 consecutive MFMAs of lane-half h
+//   B = activation patch with halo, pre-multiplied by in_scale -> LDS xs[h][PH*PW] of float4, same channel split;
+//       one ds_read_b128 per operand feeds 4 MFMAs, one ds_write_b128 pair stages 8 channels of a pixel
 //   v_mfma_f32_32x32x2_f32: lane l supplies A[o = l&31][k = l>>5] and B[k = l>>5][px = l&31];
 //   the two k of one MFMA are the channel pair (2c, 2c+1) at the SAME tap, so every LDS address is
 //   lane-base + compile-time-regular offset.  D: col = l&31 = pixel, row = (r&3)+8*(r>>2)+4*(l>>5) = o,
@@ -85,32 +87,34 @@ struct Chunk {
     static constexpr int KCP = (MODE == W2E_CONV_UP && NACC < 8 && MAXX <= 2) ? ((KC * 4 / NT_) > 16 ? 16 : (KC * 4 / NT_)) : KC;
 };
 
-// One K-chunk of MFMAs for a wave: channel pairs x taps.
+// One K-chunk of MFMAs for a wave.  LDS holds, per 8-channel sub-chunk, ws[slot][h][TN] and xs[h][plane] as float4
+// (.x.y.z.w = channel pairs c = 0..3 of lane-half h), so each b128 read feeds 4 MFMAs.
 template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX>
-__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float* ws, const float* xs, int a_base,
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4* ws, const float4* xs, int a_base,
                                            const int (&base)[NPB], int pw, int plane) {
     using T = Taps<MODE, PY, PX>;
-    // big register tiles keep the pair loop rolled: >= 32 MFMAs per iteration already hide the LDS latency
-    constexpr int WORK = NOB * NPB * T::N;
-    constexpr int UNR = WORK >= 32 ? 1 : (WORK >= 16 ? 2 : (KCP / 2 > 4 ? 4 : KCP / 2));
-#pragma unroll UNR
-    for (int c2 = 0; c2 < KCP / 2; ++c2) {
+#pragma unroll
+    for (int sub = 0; sub < KCP / 8; ++sub) {
 #pragma unroll
         for (int slot = 0; slot < T::N; ++slot) {
             const int ta = T::ta(slot), tb = T::tb(slot);
-            float av[NOB], bv[NPB];
+            float4 av[NOB], bv[NPB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (c2 * 2 * T::N + slot) * TN + ob * 32];
+            for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (sub * T::N + slot) * 2 * TN + ob * 32];
             int toff;
             if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * pw - (tb >> 1);
             else toff = ta * pw + tb;
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) bv[pb] = xs[base[pb] + c2 * 2 * plane + toff];
+            for (int pb = 0; pb < NPB; ++pb) bv[pb] = xs[base[pb] + sub * 2 * plane + toff];
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                for (int pb = 0; pb < NPB; ++pb)
-                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], bv[pb], acc[ob][pb], 0, 0, 0);
+                for (int pb = 0; pb < NPB; ++pb) {
+                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].x, bv[pb].x, acc[ob][pb], 0, 0, 0);
+                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].y, bv[pb].y, acc[ob][pb], 0, 0, 0);
+                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].z, bv[pb].z, acc[ob][pb], 0, 0, 0);
+                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].w, bv[pb].w, acc[ob][pb], 0, 0, 0);
+                }
         }
     }
 }
@@ -142,7 +146,8 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
     const int o = o_chunk * OL + ol;
     const bool ov = o < p.N;
     // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
-    const int64_t t0 = (is_row ? 6 : 2) * (int64_t)p.N, t1 = (is_row ? 7 : 5) * (int64_t)p.N, t2 = 8 * (int64_t)p.N;
+    const int64_t tap_stride = 2 * (int64_t)p.N * 4;
+    const int64_t t0 = (is_row ? 6 : 2) * tap_stride, t1 = (is_row ? 7 : 5) * tap_stride, t2 = 8 * tap_stride;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // unconditional loads at clamped positions (masked afterwards) so that the channel loop can be batched:
     // 4 channels = 36 independent loads in flight per thread instead of one dependent round trip per channel
@@ -157,7 +162,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
     const int kper = (((p.K + KG - 1) / KG) + 3) & ~3;
     const int i_lo = kg * kper, i_hi = (i_lo + kper < p.K) ? i_lo + kper : p.K;
     const float* xb = p.x + (int64_t)b * p.K * in_plane;
-    const float* wb = p.wp + (ov ? o : 0);
+    const float* wb = p.wp + (int64_t)(ov ? o : 0) * 4;  // packed [K/8][9][2][N][4]
     for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
         float xv[4][5], wv[4][3], sv[4];
 #pragma unroll
@@ -166,7 +171,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
             sv[c] = (i0 + c < i_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f) : 0.f;
 #pragma unroll
             for (int t = 0; t < 5; ++t) xv[c][t] = xb[(int64_t)i * in_plane + xoff[t]];
-            const float* wq = wb + (int64_t)i * 9 * p.N;
+            const float* wq = wb + (int64_t)(i >> 3) * 9 * 2 * p.N * 4 + (int64_t)(i & 1) * p.N * 4 + ((i & 7) >> 1);
             wv[c][0] = wq[t0], wv[c][1] = wq[t1], wv[c][2] = wq[t2];
         }
 #pragma unroll
@@ -207,9 +212,9 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     constexpr int TN = 32 * NOB * WO;
     constexpr int MAXX = max_patch_slots(MODE, 32 * NPB * WP, NT);  // activation-patch elements per thread (x KC channels)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WS_FLOATS = (MODE == W2E_CONV_UP ? 32 : KC * 9) * TN;  // every phase stages KCP*NTAPS = 32 rows
-    float* ws = smem;              // [KCP][NTAPS][TN]
-    float* xs = smem + WS_FLOATS;  // [KCP][plane]
+    constexpr int WS_FLOATS = (MODE == W2E_CONV_UP ? 32 : KC * 9) * TN;  // every phase stages KCP*NTAPS <= 32 (k,tap) rows
+    float4* ws = reinterpret_cast<float4*>(smem);              // [KCP/8][NTAPS][2][TN] float4
+    float4* xs = reinterpret_cast<float4*>(smem + WS_FLOATS);  // [KCP/8][2][plane]     float4
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -269,7 +274,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int patch = p.ph * p.pw;
     const int oy0 = (MODE == W2E_CONV_DOWN) ? 2 * r0 : r0 - 1;
     const int ox0 = (MODE == W2E_CONV_DOWN) ? 2 * c0 : c0 - 1;
-    const bool wvec = (p.N & 3) == 0;
 
     // ---- software pipeline (T14 "issue early / write late"): the global loads of chunk k+1 are issued into
     // registers right after chunk k is published to LDS and land while chunk k's MFMAs run; they are
@@ -280,9 +284,10 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         constexpr int PY = decltype(py_c)::value, PX = decltype(px_c)::value;
         using T = Taps<MODE, PY, PX>;
         constexpr int KCP = Chunk<MODE, KC, PY, PX, NOB * NPB, MAXX>::KCP;
-        constexpr int WROWS = KCP * T::N;                      // rows of the staged weight chunk
-        constexpr int WQ = (WROWS * TN / 4 + NT - 1) / NT;     // float4 weight slots per thread
-        const int a_base = half * T::N * TN + wo * NOB * 32 + j;
+        static_assert(KCP % 8 == 0, "chunks are whole 8-channel groups");
+        constexpr int WQ4 = (KCP / 8) * T::N * 2 * TN;        // float4s of the staged weight chunk
+        constexpr int WQ = (WQ4 + NT - 1) / NT;                // ... per thread
+        const int a_base = half * TN + wo * NOB * 32 + j;      // float4 index of (slot 0, h, o)
         float4 wr[WQ];
         float xr[MAXX][KCP];
         float sc[KCP];
@@ -291,22 +296,13 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #pragma unroll
             for (int t = 0; t < WQ; ++t) {
                 const int q = tid + t * NT;
-                const int r = q / (TN / 4), c4 = (q % (TN / 4)) * 4;
-                const int ci = r / T::N, slot = r % T::N;
+                const int o = q % TN, rh = q / TN;             // rh = (sub*NTAPS + slot)*2 + h
+                const int hh = rh & 1, ss = rh >> 1;
+                const int slot = ss % T::N, sub = ss / T::N;
                 const int tap = T::ta(slot) * 3 + T::tb(slot);
-                const int n = n0 + c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < WROWS * TN / 4 && k0 + ci < k_hi) {
-                    const float* wsrc = p.wp + ((int64_t)(k0 + ci) * 9 + tap) * p.N + n;
-                    if (wvec) {
-                        if (n < p.N) v = *reinterpret_cast<const float4*>(wsrc);
-                    } else {
-                        if (n < p.N) v.x = wsrc[0];
-                        if (n + 1 < p.N) v.y = wsrc[1];
-                        if (n + 2 < p.N) v.z = wsrc[2];
-                        if (n + 3 < p.N) v.w = wsrc[3];
-                    }
-                }
+                if (q < WQ4 && k0 + sub * 8 < k_hi && n0 + o < p.N)
+                    v = *reinterpret_cast<const float4*>(p.wp + ((((int64_t)((k0 >> 3) + sub) * 9 + tap) * 2 + hh) * p.N + n0 + o) * 4);
                 wr[t] = v;
             }
 #pragma unroll
@@ -329,24 +325,32 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #pragma unroll
             for (int t = 0; t < WQ; ++t) {
                 const int q = tid + t * NT;
-                if (q < WROWS * TN / 4) *reinterpret_cast<float4*>(ws + q * 4) = wr[t];
+                if (q < WQ4) ws[q] = wr[t];
             }
 #pragma unroll
             for (int t = 0; t < MAXX; ++t) {
                 const int idx = tid + t * NT;
                 if (idx < patch) {
 #pragma unroll
-                    for (int ci = 0; ci < KCP; ++ci) xs[ci * p.plane + idx] = xr[t][ci] * sc[ci];
+                    for (int sub = 0; sub < KCP / 8; ++sub) {
+                        const int c0 = sub * 8;
+                        xs[(sub * 2 + 0) * p.plane + idx] = make_float4(xr[t][c0] * sc[c0], xr[t][c0 + 2] * sc[c0 + 2],
+                                                                         xr[t][c0 + 4] * sc[c0 + 4], xr[t][c0 + 6] * sc[c0 + 6]);
+                        xs[(sub * 2 + 1) * p.plane + idx] = make_float4(xr[t][c0 + 1] * sc[c0 + 1], xr[t][c0 + 3] * sc[c0 + 3],
+                                                                         xr[t][c0 + 5] * sc[c0 + 5], xr[t][c0 + 7] * sc[c0 + 7]);
+                    }
                 }
             }
         };
 
         prefetch(k_lo);
         for (int k0 = k_lo; k0 < k_hi; k0 += KCP) {
-            __syncthreads();  // everyone finished reading the previous chunk
-            commit();
-            __syncthreads();
-            if (k0 + KCP < k_hi) prefetch(k0 + KCP);
+            if (!(p.tune_skip & 4) || k0 == k_lo) {  // tuning aid: bit 2 = stage only the first chunk
+                __syncthreads();  // everyone finished reading the previous chunk
+                commit();
+                __syncthreads();
+                if (k0 + KCP < k_hi) prefetch(k0 + KCP);
+            }
             mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane);
         }
     };
@@ -455,18 +459,25 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     }
 }
 
+// weight [cout,cin,3,3] -> wp [ceil(K/8)][9][2][N][4]: element (kc, tap, h, n, c) = scale * W(k = 8*kc + 2*c + h, tap', n)
+// (zero where k >= K), K/N = cin/cout (transpose=0) or cout/cin (transpose=1), tap' = 8-tap when flip.
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, float scale,
                                  int transpose, int flip) {
-    const int64_t total = (int64_t)cout * cin * 9;
     const int Kd = transpose ? cout : cin, Nd = transpose ? cin : cout;
+    const int64_t total = (int64_t)((Kd + 7) / 8) * 9 * 2 * Nd * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(e % Nd);
-        const int tap = (int)((e / Nd) % 9);
-        const int k = (int)(e / ((int64_t)Nd * 9));
-        const int o = transpose ? k : n, i = transpose ? n : k;
-        const int st = flip ? 8 - tap : tap;
-        wp[e] = scale * w[((int64_t)o * cin + i) * 9 + st];
-        (void)Kd;
+        const int c = (int)(e & 3);
+        const int n = (int)((e >> 2) % Nd);
+        const int hh = (int)((e / (4 * (int64_t)Nd)) & 1);
+        const int tap = (int)((e / (8 * (int64_t)Nd)) % 9);
+        const int kc = (int)(e / (72 * (int64_t)Nd));
+        const int k = kc * 8 + 2 * c + hh;
+        float v = 0.f;
+        if (k < Kd) {
+            const int o = transpose ? k : n, i = transpose ? n : k;
+            v = scale * w[((int64_t)o * cin + i) * 9 + (flip ? 8 - tap : tap)];
+        }
+        wp[e] = v;
     }
 }
 
@@ -476,6 +487,13 @@ struct TileCfg {
 
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
 static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {  // dynamic LDS above 64 KB is opt-in per kernel (gfx950: 160 KB per CU)
+        static size_t allowed = 0;
+        if (lds > allowed &&
+            hipFuncSetAttribute((const void*)modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
+            allowed = 150 * 1024;
+    }
     modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC><<<grid, 64 * WO * WP, lds, s>>>(p);
 }
 
@@ -491,13 +509,16 @@ static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipS
         case 6: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
         case 7: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
         case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC>(p, grid, lds, s); return true;
+        case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC>(p, grid, lds, s); return true;
+        case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC>(p, grid, lds, s); return true;
     }
     return false;
 }
 
 static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},               // 512 threads, 1 workgroup / CU
-                                   {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4}};  // 256 threads
-static const int kNumCfg = 9;
+                                   {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4},  // 256 threads
+                                   {2, 2, 2, 4}, {2, 2, 1, 8}};  // 512 threads, 4 accumulators per wave (register headroom)
+static const int kNumCfg = 11;
 
 static int next_pow2(int v) {
     int r = 1;
@@ -513,7 +534,7 @@ extern "C" int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, 
                              void* stream) {
     W2E_REQUIRE(weight && wp, "conv_pack: null tensor");
     W2E_REQUIRE(cout > 0 && cin > 0, "conv_pack: bad dims");
-    const int64_t total = (int64_t)cout * cin * 9;
+    const int64_t total = (int64_t)(((transpose ? cout : cin) + 7) / 8) * 72 * (transpose ? cin : cout) * 4;
     conv_pack_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(weight, wp, cout, cin, scale, transpose,
                                                                              flip);
     W2E_LAUNCH_CHECK("conv_pack");
@@ -549,7 +570,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     const bool up = mode == W2E_CONV_UP;
     const TileCfg* cfgs = kCfgStd;
     const int ncfg = kNumCfg;
-    const int kc = mode == W2E_CONV_DOWN ? 4 : 8;
+    const int kc = 8;  // channels per K-chunk = one float4 group per lane-half
     const int kc_max = up ? 16 : kc;  // deepest chunk any workgroup of this launch uses
     const int wp2 = next_pow2(w);
     int best = -1, best_splits = 1;
@@ -566,7 +587,8 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const int kdeep = (up && cfgs[c].nob * cfgs[c].npb < 8 && max_patch_slots(mode, tm, nt) <= 2) ? 16 : kc;
         const size_t lds_c = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep * ph * pw)
                                 : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw);
-        if (lds_c > 64 * 1024) continue;
+        if (lds_c > 150 * 1024) continue;
+        if (mode == W2E_CONV_DOWN && max_patch_slots(mode, tm, nt) * (cfgs[c].nob * cfgs[c].npb >= 8 ? 2 : 1) > 5) continue;  // prefetch registers: 8 channels x slots
         if (ph * pw > nt * max_patch_slots(mode, tm, nt)) continue;  // register-prefetch slots per thread
         const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
         const double waves_per_simd = nt / 256.0;
@@ -583,8 +605,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
             } else {
                 cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + t_stage) / sp + 4000.0);  // + prologue/epilogue per workgroup
             }
-            if (sp > 1) cost += 6000.0;  // memset + atomics + (with act) the separate bias/act pass
-            if (best < 0 || cost < best_cost * 0.97) best = c, best_cost = cost, best_splits = sp;
+            if (sp > 1) cost = cost * 1.06 + 8000.0;  // memset + atomics + (with act) the separate bias/act pass
+            if (cfgs[c].nob * cfgs[c].npb >= 8 && nt == 512 && mode != W2E_CONV_UP) cost *= 1.0;
+            if (best < 0 || cost < best_cost * 0.995) best = c, best_cost = cost, best_splits = sp;
         }
     }
     if (const char* sk = getenv("W2E_TUNE_SKIP")) p.tune_skip = atoi(sk);
@@ -592,6 +615,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         int fc = -1, fs = 1;
         if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < ncfg) best = fc, best_splits = fs > 0 ? fs : 1;
     }
+    if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "modconv mode %d K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
     const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * cfg.npb * cfg.wp;
@@ -611,7 +635,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
                     : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
-    W2E_REQUIRE(lds <= 64 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
+    W2E_REQUIRE(lds <= 150 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
     p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), kc_max) * kc_max);
     p.splits = (int)ceil_div(k_ch, p.k_per);
     if (up) {
@@ -634,8 +658,8 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     } else if (up) {
         ok = launch_mode<W2E_CONV_UP, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
     } else {
-        if (dot_with) ok = launch_mode<W2E_CONV_DOWN, EPI_DOT, 4>(best, p, (int)grid, lds, s);
-        else ok = launch_mode<W2E_CONV_DOWN, EPI_PLAIN, 4>(best, p, (int)grid, lds, s);
+        if (dot_with) ok = launch_mode<W2E_CONV_DOWN, EPI_DOT, 8>(best, p, (int)grid, lds, s);
+        else ok = launch_mode<W2E_CONV_DOWN, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
     }
     W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
     W2E_LAUNCH_CHECK("modconv3x3");

@@ -116,10 +116,10 @@ def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
 
 # ------------------------------------------------------------------------------------------ K1
 def conv_pack(weight, scale, transpose, flip):
-    """weight [Cout,Cin,3,3] -> [K][9][N] (w2e_conv_pack)."""
+    """weight [Cout,Cin,3,3] -> [ceil(K/8)][9][2][N][4] (w2e_conv_pack): K the reduced, N the produced channels."""
     cout, cin = weight.shape[0], weight.shape[1]
-    wp = torch.empty(((cout if transpose else cin), 9, (cin if transpose else cout)), device=weight.device,
-                     dtype=torch.float32)
+    kd, nd = (cout, cin) if transpose else (cin, cout)
+    wp = torch.empty(((kd + 7) // 8, 9, 2, nd, 4), device=weight.device, dtype=torch.float32)
     call("w2e_conv_pack", ptr(_c(weight.detach())), ptr(wp), cout, cin, float(scale), int(transpose), int(flip),
          stream_ptr())
     return wp
@@ -131,9 +131,9 @@ MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None):
     """One call of w2e_modconv3x3.  h,w: input size for SAME/UP, output size for DOWN."""
     b, k = x.shape[0], x.shape[1]
-    n = wp.shape[2]
-    if wp.shape[0] != k:
-        raise RuntimeError(f"modconv: packed weight expects {wp.shape[0]} input channels, got {k}")
+    n = wp.shape[3]
+    if wp.shape[0] != (k + 7) // 8:
+        raise RuntimeError(f"modconv: packed weight holds {wp.shape[0]} 8-channel groups, input has {k} channels")
     if mode == MODE_UP:  # phase-planar T: T[Y][X] = y[Y&1][X&1][Y>>1][X>>1]  (unit-stride stores per output phase)
         y = torch.empty((b, n, 2, 2, h + 1, (w + 4) & ~3), device=x.device, dtype=torch.float32)  # 16-B aligned rows
     else:
