@@ -388,3 +388,46 @@ def test_id_preprocess_golden_and_adjoint(size, key, gkey, b):
     io = img.clone().requires_grad_(True)
     (go,) = torch.autograd.grad(O.id_preprocess(io), io, gy)
     assert_close(gx, go, 1e-5, "adjoint")
+
+
+@pytest.mark.parametrize("cin,cout,h,up", [(32, 32, 1024, False), (64, 32, 512, True), (512, 512, 64, False)])
+def test_modconv_full_size_properties(cin, cout, h, up):
+    """BASELINE-size layers (too big for the CPU oracle in a test): size-independent properties of the modulated conv.
+    (1) demodulation makes the output invariant to a rescaling of the style; (2) the layer is linear in x;
+    (3) the input-gradient kernel is the exact adjoint: <y(x), g> == <x, dx(g)>; (4) a strided sample of the
+    output equals the oracle evaluated on the receptive-field crop."""
+    from where2edit_amd import functional as K
+    b = 2
+    w = torch.randn(cout, cin, 3, 3, device=DEV)
+    scale = (cin * 9) ** -0.5
+    packs = (K.conv_pack(w, scale, False, False), K.conv_pack(w, scale, True, not up))
+    wsq = (w * scale).square().sum((2, 3)).contiguous()
+    blur = cu(seeded.fir_kernel(gain=4.0)) if up else None
+    x = torch.randn(b, cin, h, h, device=DEV)
+    s = torch.randn(b, cin, device=DEV) + 1.0
+    y = K.modconv(x, s, wsq, packs, blur, up)
+    oh = 2 * h if up else h
+    assert y.shape == (b, cout, oh, oh)
+    y2 = K.modconv(x, 3.0 * s, wsq, packs, blur, up)                      # (1)
+    assert rel_err(y2, y) < 2e-5
+    y3 = K.modconv(-2.0 * x, s, wsq, packs, blur, up)                     # (2)
+    assert rel_err(y3, -2.0 * y) < 1e-5
+    xg = x.clone().requires_grad_(True)                                    # (3)
+    g = torch.randn_like(y)
+    (dx,) = torch.autograd.grad(K.modconv(xg, s, wsq, packs, blur, up), xg, g)
+    lhs, rhs = (y.double() * g.double()).sum(), (x.double() * dx.double()).sum()
+    assert abs(lhs - rhs) <= 1e-5 * (y.double().abs() * g.double().abs()).sum()
+    # (4) 8x8 output crop at an interior position against the oracle on the input crop that feeds it
+    c0 = h // 2 - (h // 2) % 2
+    halo = 4
+    xc = x[:1, :, c0 - halo:c0 + 8 + halo, c0 - halo:c0 + 8 + halo].cpu()
+    sc = s[:1].cpu().view(1, 1, cin, 1, 1)
+    ref, _ = OG.modulated_conv2d(xc, sc, w.cpu()[None], None, None, demodulate=True, upsample=up,
+                                 input_is_stylespace=True, blur_kernel=seeded.fir_kernel(gain=4.0) if up else None)
+    if up:
+        got = y[:1, :, 2 * c0:2 * c0 + 16, 2 * c0:2 * c0 + 16]
+        ref = ref[:, :, 2 * halo:2 * halo + 16, 2 * halo:2 * halo + 16]
+    else:
+        got = y[:1, :, c0:c0 + 8, c0:c0 + 8]
+        ref = ref[:, :, halo:halo + 8, halo:halo + 8]
+    assert_close(got, ref, FWD_TOL, "crop vs oracle")
