@@ -45,8 +45,9 @@ constexpr int MAX_TILE_K = 8;    // taps per axis the tile kernel handles (pitch
 // up = down = 1.  The (TH+kh-1) x (TW+kw-1) input tile is staged once into LDS (row pitch a multiple of 4
 // floats so each thread's window rows are 16-B aligned: ds_read_b128), every thread then slides the taps
 // over a register window: 2*(kw+3) LDS floats read per 8 outputs.
-// 4x4 FIR (the generator's blur), up = down = 1: taps in registers, everything unrolled, ACT compile-time.
-template <bool ACT, bool PLANAR, bool VEC>
+// 4x4 FIR (the generator's blur), up = down = 1, unaligned source rows (odd widths): scalar staging; taps in
+// registers, everything unrolled, ACT compile-time.  Aligned sources take upfirdn_blur4_kernel below.
+template <bool ACT>
 __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;
@@ -63,68 +64,20 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
         const int plane = t / tiles_per_plane;
         const int rem = t - plane * tiles_per_plane;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int hp = (p.in_h + 1) >> 1, wp = (p.in_w + 1) >> 1;
-        const float* src = p.x + (int64_t)plane * (PLANAR ? 4 * hp * ((wp + 3) & ~3) : p.in_h * p.in_w);
+        const float* src = p.x + (int64_t)plane * p.in_h * p.in_w;
         const int oy0 = ty * TH, ox0 = tx * TW;
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
         __syncthreads();  // previous iteration's readers are done
-        if (PLANAR) {
-            // x'[Y&1][X&1][Y>>1][X>>1] with a 16-B aligned row pitch wpp: each tile row is two unit-stride runs (one
-            // per column parity), read as aligned float4s; the interleave happens in the LDS write.
-            const int wpp = (wp + 3) & ~3;
-            constexpr int NQ = ((PW + 1) / 2 + 1 + 3) / 4 + 1;  // float4s covering one parity run of a tile row
 #pragma unroll
-            for (int it = 0; it < (PH * 2 * NQ + 255) / 256; ++it) {
-                const int i = tid + it * 256;
-                const int r = i / (2 * NQ), rem = i - r * (2 * NQ);
-                const int par = rem / NQ, q = rem - par * NQ;
-                const int iy = iy0 + r;
-                const int v_lo = (ix0 - par + 1) >> 1;            // first v with 2v+par >= ix0 (arithmetic shift: floor)
-                const int v4 = (v_lo & ~3) + 4 * q;               // aligned chunk start
-                const bool row_ok = r < PH && iy >= 0 && iy < p.in_h;
-                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy);
-                const float* rowp = src + (((cy & 1) * 2 + par) * hp + (cy >> 1)) * wpp;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(p.tune & 1) && row_ok && v4 >= 0 && v4 + 3 < wpp) v = *reinterpret_cast<const float4*>(rowp + v4);
-                const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ix = 2 * (v4 + k) + par, c = ix - ix0;
-                    if (r < PH && c >= 0 && c < PW) tile[r * PITCH + c] = (row_ok && ix >= 0 && ix < p.in_w) ? e[k] : 0.f;
-                }
-            }
-        } else if (VEC) {
-            // rows of the plain image are 16-B aligned (in_w % 4 == 0): aligned float4 reads of the covering span
-            constexpr int NQ = (PW + 3) / 4 + 1;
-            const int xa = ix0 & ~3;
-#pragma unroll
-            for (int it = 0; it < (PH * NQ + 255) / 256; ++it) {
-                const int i = tid + it * 256;
-                const int r = i / NQ, q = i - r * NQ;
-                const int iy = iy0 + r, x4 = xa + 4 * q;
-                const bool row_ok = r < PH && iy >= 0 && iy < p.in_h;
-                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(p.tune & 1) && row_ok && x4 >= 0 && x4 + 3 < p.in_w) v = *reinterpret_cast<const float4*>(src + cy * p.in_w + x4);
-                const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = x4 + k - ix0;
-                    if (r < PH && c >= 0 && c < PW) tile[r * PITCH + c] = e[k];  // out-of-image chunks stay 0
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < (PH * PW + 255) / 256; ++it) {
-                const int i = tid + it * 256;
-                const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * PW;
-                const int iy = iy0 + r, ix = ix0 + c;
-                const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-                // branch-free: load from a clamped (always valid) address, then select
-                const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
-                const float v = (p.tune & 1) ? 1.f : src[cy * p.in_w + cx];
-                if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
-            }
+        for (int it = 0; it < (PH * PW + 255) / 256; ++it) {
+            const int i = tid + it * 256;
+            const int r = (int)__umulhi((unsigned)i, pw_magic), c = i - r * PW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            // branch-free: load from a clamped (always valid) address, then select
+            const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
+            const float v = (p.tune & 1) ? 1.f : src[cy * p.in_w + cx];
+            if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
         }
         __syncthreads();
         float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -172,6 +125,158 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
                 for (int j = 0; j < 4; ++j)
                     if (ox + j < p.out_w) dst[j] = v[j];
             }
+        }
+    }
+}
+
+// 4x4 FIR, up = down = 1, input rows 16-B aligned (plain layout with in_w % 4 == 0, or the phase-planar T'): the two
+// HBM-heavy blur shapes of a step.
+//  * A workgroup owns one 64-column strip of tiles (fixed tile column) and walks down (plane, tile row) items, so
+//    everything that depends on the column -- chunk offsets, edge masks, LDS addresses -- is computed once.
+//  * Staging is a pure copy: an aligned global float4 becomes one conflict-free ds_write_b128 into an LDS row that
+//    keeps the SOURCE's alignment (and, for the planar layout, its even/odd column split).  The realignment /
+//    interleave happens when the threads read their windows: lanes run along x (stride-1 LDS reads, 256-B
+//    coalesced stores even for odd output widths), 8 output rows per thread.
+//  * The next item's float4s are fetched into registers before the current one is filtered and stored
+//    (issue early / write late).
+template <bool ACT, bool PLANAR>
+__global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PW = TW + 3, PH = TH + 3;
+    constexpr int NQ = PLANAR ? ((PW + 1) / 2 + 1 + 3) / 4 + 1 : (PW + 3) / 4 + 1;  // float4s per staged row (per parity)
+    constexpr int PE = 4 * NQ;
+    constexpr int SLOTS = (PLANAR ? 2 : 1) * PH * NQ;
+    constexpr int NIT = (SLOTS + 255) / 256;
+    static_assert(TW == 64 && TH == 32, "thread mapping: 64 lanes along x, 4 waves x 8 rows");
+    const int tid = threadIdx.x;
+    float kr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kr[i] = p.flip ? p.kern[15 - i] : p.kern[i];
+    const float nw = (ACT && p.noise) ? p.noise_w[0] : 0.f;
+    const int hp = (p.in_h + 1) >> 1, wpp = (((p.in_w + 1) >> 1) + 3) & ~3;
+    const int64_t plane_stride = PLANAR ? (int64_t)4 * hp * wpp : (int64_t)p.in_h * p.in_w;
+    const int row_len = PLANAR ? wpp : p.in_w;                       // floats per source row (a multiple of 4)
+    const int item_stride = PLANAR ? (TH / 2) * wpp : TH * p.in_w;   // source offset between vertically adjacent tiles
+
+    const int tx = blockIdx.x % tiles_x, g0 = blockIdx.x / tiles_x, gstep = gridDim.x / tiles_x;
+    const int ox0 = tx * TW, ix0 = ox0 - p.pad_x0;
+    const int n_items = (int)p.planes * tiles_y;
+    // first source column index of chunk 0 of parity par
+    auto chunk0 = [&](int par) { return PLANAR ? (((ix0 - par + 1) >> 1) & ~3) : (ix0 & ~3); };
+
+    // per-slot constants: slot -> (staged row r, parity, chunk q)
+    int s_r[NIT], s_src[NIT], s_lds[NIT];
+    unsigned s_mask[NIT];  // bit k: element k of the chunk is image data (column inside [0, in_w))
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
+        int r, par, q;
+        if (PLANAR) {
+            r = i / (2 * NQ);
+            const int rem = i - r * (2 * NQ);
+            par = rem / NQ, q = rem - par * NQ;
+        } else {
+            r = i / NQ, par = 0, q = i - r * NQ;
+        }
+        const int v4 = chunk0(par) + 4 * q;
+        const bool col_ok = r < PH && v4 >= 0 && v4 + 3 < row_len;
+        unsigned m = 0;
+        if (col_ok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ix = PLANAR ? 2 * (v4 + k) + par : v4 + k;
+                if (ix >= 0 && ix < p.in_w) m |= 1u << k;
+            }
+        }
+        const int ry = r - p.pad_y0;  // source row relative to the tile's first output row (TH is even: parity is fixed)
+        s_r[it] = r;
+        s_mask[it] = m;
+        s_src[it] = PLANAR ? ((((ry & 1) * 2 + par) * hp + (ry >> 1)) * wpp + v4) : (ry * p.in_w + v4);
+        s_lds[it] = (par * PH + (r < PH ? r : 0)) * PE + 4 * q;
+    }
+
+    auto fetch = [&](int item, float4 (&reg)[NIT]) __attribute__((always_inline)) {
+        const int plane = item / tiles_y, ty = item - plane * tiles_y;
+        const float* base = p.x + (int64_t)plane * plane_stride + (int64_t)ty * item_stride;
+        const int iy0 = ty * TH - p.pad_y0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int iy = iy0 + s_r[it];
+            const bool ok = s_mask[it] != 0 && iy >= 0 && iy < p.in_h && !(p.tune & 1);
+            // branch-free: always load from a valid address (the slot's own, or the tile base), select afterwards
+            const float4 v = *reinterpret_cast<const float4*>(ok ? base + s_src[it] : p.x);
+            reg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](const float4 (&reg)[NIT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (NIT * 256 > SLOTS && s_r[it] >= PH) continue;
+            float4 v = reg[it];
+            if (PLANAR) {  // the padded tail of a source row is not image data
+                if (!(s_mask[it] & 1u)) v.x = 0.f;
+                if (!(s_mask[it] & 2u)) v.y = 0.f;
+                if (!(s_mask[it] & 4u)) v.z = 0.f;
+                if (!(s_mask[it] & 8u)) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(smem + s_lds[it]) = v;
+        }
+    };
+
+    // window of the thread: image columns a .. a+3 (a = ix0 + lane), staged rows yb .. yb+10
+    const int lane = tid & 63, yb = (tid >> 6) * 8;
+    int woff[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+        const int c = ix0 + lane + kx;
+        woff[kx] = PLANAR ? ((c & 1) * PH * PE + (c >> 1) - chunk0(c & 1)) : (c - chunk0(0));
+    }
+    const int ox = ox0 + lane;
+    const bool x_ok = ox < p.out_w;
+
+    float4 reg[NIT];
+    int item = g0;
+    if (item < n_items) fetch(item, reg);
+    for (; item < n_items; item += gstep) {
+        __syncthreads();  // the previous tile's readers are done
+        commit(reg);
+        __syncthreads();
+        if (item + gstep < n_items) fetch(item + gstep, reg);  // lands while this tile is filtered and stored
+
+        const int plane = item / tiles_y, ty = item - plane * tiles_y;
+        const int oy0 = ty * TH + yb;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {  // staged row yb+r feeds output row j with ky = r - j
+            if ((p.tune & 2) && r > 0) break;
+            const float* rowp = smem + (yb + r) * PE;
+            const float w0 = rowp[woff[0]], w1 = rowp[woff[1]], w2 = rowp[woff[2]], w3 = rowp[woff[3]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ky = r - j;
+                if (ky >= 0 && ky < 4)
+                    acc[j] += kr[ky * 4 + 0] * w0 + kr[ky * 4 + 1] * w1 + kr[ky * 4 + 2] * w2 + kr[ky * 4 + 3] * w3;
+            }
+        }
+        float e_scale = 1.f, e_bias = 0.f;
+        if (ACT) {
+            if (p.out_scale) e_scale = p.out_scale[plane];
+            if (p.bias) e_bias = p.bias[plane % p.channels];
+        }
+        float nz[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            nz[j] = (ACT && p.noise && x_ok && oy0 + j < p.out_h) ? p.noise[(oy0 + j) * p.out_w + ox] : 0.f;
+        float* dst = p.y + ((int64_t)plane * p.out_h + oy0) * p.out_w + ox;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float e = acc[j];
+            if (ACT) {
+                e = e * e_scale + e_bias + nw * nz[j];
+                e = (e > 0.f ? e : e * p.slope) * p.gain;
+            }
+            if ((p.tune & 4) && e != 123456.75f) continue;
+            if (x_ok && oy0 + j < p.out_h) dst[j * p.out_w] = e;
         }
     }
 }
@@ -298,15 +403,26 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
         const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)pw + 1);
         if (kh == 4 && kw == 4) {
             const bool vec = !in_layout && (in_w & 3) == 0 && ((uintptr_t)x & 15) == 0;
-            if (in_layout) {
-                if (act) upfirdn_tile4_kernel<true, true, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-                else upfirdn_tile4_kernel<false, true, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-            } else if (vec) {
-                if (act) upfirdn_tile4_kernel<true, false, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-                else upfirdn_tile4_kernel<false, false, true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+            if (in_layout || vec) {
+                // aligned-source kernel: each workgroup walks (plane, tile row) items of one tile column; ~8 per CU
+                const int64_t items = planes * tiles_y;
+                int gsteps = 256 * 8 / tiles_x;
+                if (gsteps < 1) gsteps = 1;
+                if (gsteps > items) gsteps = (int)items;
+                const int g2 = gsteps * tiles_x;
+                constexpr int PWc = TW + 3, PHc = TH + 3;
+                const size_t lds2 = in_layout ? sizeof(float) * 2 * PHc * 4 * (((PWc + 1) / 2 + 1 + 3) / 4 + 1)
+                                              : sizeof(float) * PHc * 4 * ((PWc + 3) / 4 + 1);
+                if (in_layout) {
+                    if (act) upfirdn_blur4_kernel<true, true><<<g2, 256, lds2, s>>>(p, tiles_x, tiles_y);
+                    else upfirdn_blur4_kernel<false, true><<<g2, 256, lds2, s>>>(p, tiles_x, tiles_y);
+                } else {
+                    if (act) upfirdn_blur4_kernel<true, false><<<g2, 256, lds2, s>>>(p, tiles_x, tiles_y);
+                    else upfirdn_blur4_kernel<false, false><<<g2, 256, lds2, s>>>(p, tiles_x, tiles_y);
+                }
             } else {
-                if (act) upfirdn_tile4_kernel<true, false, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
-                else upfirdn_tile4_kernel<false, false, false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                if (act) upfirdn_tile4_kernel<true><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
+                else upfirdn_tile4_kernel<false><<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
             }
         } else {
             upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
