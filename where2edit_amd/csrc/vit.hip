@@ -17,10 +17,21 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 }
 
 // ------------------------------------------------------------------------------------------ GEMM
-// 64x64 output tile per 256-thread workgroup, 4 waves as 2(m) x 2(n), each one 32x32 accumulator of
-// v_mfma_f32_32x32x2_f32.  C rows come from the A operand, C columns (contiguous in memory) sit on the
-// lanes.  K is consumed in 32-deep tiles, software-pipelined through registers like the conv kernel.
-constexpr int GBM = 64, GBN = 64, GBK = 32, GPA = GBK + 1;  // +1 pad: conflict-free column reads
+// M = 50*batch rows is a skinny GEMM: a handful of tiles, each a long dependent chain of K-steps whose cost is one
+// HBM/L2 round trip.  So the kernel is built around (a) full-line loads with many bytes in flight per step, (b) few
+// steps per workgroup, (c) enough workgroups to fill the chip:
+//   * tile 64(M) x 64(N) per 256-thread workgroup, 4 waves as 2(m) x 2(n), each one 32x32 accumulator of
+//     v_mfma_f32_32x32x2_f32 (C rows come from A, C columns -- contiguous in memory -- sit on the lanes); small tiles
+//     keep split-K -- whose fp32 atomics cost ~50 ns per 256-B wave-instruction per CU -- to the N = 768 shapes;
+//   * K in 64-deep steps: 16 lanes x 16 B read one operand row's whole 256-B slice, 8 float4 per thread in flight;
+//     two LDS stages, ONE barrier per step: while the MFMAs of step t run out of one stage, the registers holding
+//     step t+1 are written to the other one in the shadow of the matrix pipe, then step t+2's loads are issued;
+//   * operands sit in LDS in the order the MFMA eats them -- float4 (g, h, row) = the 4 k-pairs {8g+2s+h, s=0..3} of
+//     one row -- so one ds_read_b128 per operand feeds 4 MFMAs; those reads run one k-group ahead of the MFMAs;
+//   * split-K over blockIdx.z (fp32 atomics onto a zeroed C) sized by the host so that the grid is ~one workgroup per
+//     CU and every workgroup runs only a few K-steps.
+constexpr int GBM = 64, GBN = 64, GBK = 64;
+constexpr int GPA = GBM + 1, GPB = GBN + 1;  // float4s per (g, h) plane (+1 pad)
 
 struct GemmParams {
     const float* a;
@@ -33,89 +44,177 @@ struct GemmParams {
     int k_per;  // K range of one blockIdx.z slice (split-K); == k when gridDim.z == 1
 };
 
+// One K-step of both operands in flight: the raw float4s as loaded plus the K-tail masks that are applied when the
+// registers are written to LDS (NOT at the load: any use of a loaded value at the issue site makes the wave wait there).
+struct GemmRegs {
+    float4 a[GBM / 16];
+    float4 b[4];
+    unsigned ka;     // all-ones where this thread's K positions of the [rows,K] operands are real
+    unsigned kb[4];  // likewise for the 4 k-rows of a [K,N] B operand
+};
+
 template <bool TRANS_B, bool A_GELU>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-    __shared__ float As[GBM * GPA];
-    __shared__ float Bs[TRANS_B ? GBN * GPA : GBK * GBN];
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 gsm[];  // 2 stages x { A [g = 0..7][h = 0..1][row], B likewise }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Four accumulators for ONE 32x32 output block, one per k-pair slot of a group: back-to-back MFMAs into the same
+    // accumulator run at half rate (~130 cycles each instead of 64: the next one waits for the write-back), and with one
+    // wave per SIMD nothing else fills the gap.  They are summed in the epilogue.
+    f32x16 acc4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
 
+    // staging roles.  [rows,K] operands (A, and B when TRANS_B): thread = (row = tid/16 (+16 per pass), 4 consecutive k
+    // at 4*(tid%16)): a wave-instruction reads 4 whole 256-B row slices.  [K,N] B: thread = (gh = tid/16, c4 = tid%16)
+    // reads the 4 k-rows {8g+2s+h} of 4 consecutive columns (whole 256-B lines again) and transposes in registers.
+    // Branch-free: out-of-range ROWS / COLUMNS are clamped to a valid one (they only feed accumulator rows / columns
+    // that are never stored); an out-of-range K position is read from a clamped address and masked at the LDS write.
+    const int s_row = tid >> 4, s_l = tid & 15;
+    auto prefetch = [&](int k0, GemmRegs& R) __attribute__((always_inline)) {
+        const int kk = k0 + 4 * s_l;
+        const bool k_ok = kk < p.k;
+        const int kc = k_ok ? kk : 0;
+        R.ka = k_ok ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int it = 0; it < GBM / 16; ++it) {
+            const int row = m0 + s_row + 16 * it;
+            R.a[it] = *reinterpret_cast<const float4*>(p.a + (int64_t)(row < p.m ? row : p.m - 1) * p.lda + kc);
+        }
+        if (TRANS_B) {
+#pragma unroll
+            for (int it = 0; it < GBN / 16; ++it) {
+                const int row = n0 + s_row + 16 * it;
+                R.b[it] = *reinterpret_cast<const float4*>(p.b + (int64_t)(row < p.n ? row : p.n - 1) * p.ldb + kc);
+            }
+        } else {
+            const int kb = k0 + 8 * (s_row >> 1) + (s_row & 1);
+            const int col = n0 + 4 * s_l < p.n ? n0 + 4 * s_l : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool kq_ok = kb + 2 * q < p.k;
+                R.kb[q] = kq_ok ? 0xffffffffu : 0u;
+                R.b[q] = *reinterpret_cast<const float4*>(p.b + (int64_t)(kq_ok ? kb + 2 * q : 0) * p.ldb + col);
+            }
+        }
+    };
+    auto msk = [](float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); };
+    // a float4 of 4 consecutive k (k%8 = 0 or 4) is two half-float4s of the LDS image: {k, k+2} -> h=0, {k+1, k+3} -> h=1
+    const int w_g = s_l >> 1, w_s = (s_l & 1) * 2;
+    // One piece of the register -> LDS write pass (8 pieces per K-step: 4 A row-passes, 4 B); the pieces are dealt to
+    // the MFMA groups of the step before, so the LDS writes (and the QuickGELU prologue) issue in the shadow of the
+    // matrix pipe.
+    auto commit_piece = [&](int piece, const GemmRegs& R, float4* As4, float4* Bs4) __attribute__((always_inline)) {
+        if (piece < GBM / 16) {
+            const int it = piece;
+            float4 v = R.a[it];
+            v.x = msk(v.x, R.ka), v.y = msk(v.y, R.ka), v.z = msk(v.z, R.ka), v.w = msk(v.w, R.ka);
+            if (A_GELU) v.x = quick_gelu(v.x), v.y = quick_gelu(v.y), v.z = quick_gelu(v.z), v.w = quick_gelu(v.w);
+            const int row = s_row + 16 * it;
+            float* d0 = reinterpret_cast<float*>(As4 + (w_g * 2 + 0) * GPA + row) + w_s;
+            float* d1 = reinterpret_cast<float*>(As4 + (w_g * 2 + 1) * GPA + row) + w_s;
+            *reinterpret_cast<float2*>(d0) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2*>(d1) = make_float2(v.y, v.w);
+        } else if (TRANS_B) {
+            const int it = piece - GBM / 16;
+            const int row = s_row + 16 * it;
+            float* d0 = reinterpret_cast<float*>(Bs4 + (w_g * 2 + 0) * GPB + row) + w_s;
+            float* d1 = reinterpret_cast<float*>(Bs4 + (w_g * 2 + 1) * GPB + row) + w_s;
+            *reinterpret_cast<float2*>(d0) = make_float2(msk(R.b[it].x, R.ka), msk(R.b[it].z, R.ka));
+            *reinterpret_cast<float2*>(d1) = make_float2(msk(R.b[it].y, R.ka), msk(R.b[it].w, R.ka));
+        } else {
+            const int c = piece - GBM / 16;
+            float4* d = Bs4 + s_row * GPB + 4 * s_l;
+            const unsigned* km = R.kb;
+            if (c == 0) d[0] = make_float4(msk(R.b[0].x, km[0]), msk(R.b[1].x, km[1]), msk(R.b[2].x, km[2]), msk(R.b[3].x, km[3]));
+            if (c == 1) d[1] = make_float4(msk(R.b[0].y, km[0]), msk(R.b[1].y, km[1]), msk(R.b[2].y, km[2]), msk(R.b[3].y, km[3]));
+            if (c == 2) d[2] = make_float4(msk(R.b[0].z, km[0]), msk(R.b[1].z, km[1]), msk(R.b[2].z, km[2]), msk(R.b[3].z, km[3]));
+            if (c == 3) d[3] = make_float4(msk(R.b[0].w, km[0]), msk(R.b[1].w, km[1]), msk(R.b[2].w, km[2]), msk(R.b[3].w, km[3]));
+        }
+    };
+    constexpr int STAGE = (GBK / 4) * (GPA + GPB);
+    constexpr int NPIECE = GBM / 16 + 4;
+    static_assert(NPIECE % 4 == 0, "pieces are dealt to the last 4 MFMA groups");
+
+    // The slice runs an EVEN number of K-steps (k_per is a multiple of 128; past K the masks feed zeros), and every
+    // step issues its prefetch unconditionally (a finished slice re-reads its first tile and drops it): a prefetch
+    // under a condition, or a conditional second half of the unrolled loop, makes hipcc merge "loaded" and "kept"
+    // values right after the loads -- which puts a vmcnt wait at the issue site and serialises the pipeline.
+    const int k_lo = blockIdx.z * p.k_per;
+    const int k_hi = (k_lo + p.k_per < p.k) ? k_lo + p.k_per : ((p.k - k_lo + 2 * GBK - 1) / (2 * GBK)) * (2 * GBK) + k_lo;
+
+    // K-step t: MFMAs out of LDS stage t&1.  Its loads were issued at the START of step t-2 into register set t&1 and
+    // written to the stage during the second half of step t-1 -- a step and a half of MFMAs to cover the round trip.
+    // `Rload` = the set to refill with step t+2 (it held step t, already in LDS), `Rnext` = the set holding step t+1.
+    auto step = [&](int k0, int stage, GemmRegs& Rload, const GemmRegs& Rnext) __attribute__((always_inline)) {
+        prefetch(k0 + 2 * GBK < k_hi ? k0 + 2 * GBK : k_lo, Rload);
+        const float4* As4 = gsm + stage * STAGE;
+        const float4* Bs4 = As4 + (GBK / 4) * GPA;
+        float4* An = gsm + (stage ^ 1) * STAGE;  // the other stage: every wave left it at the barrier that ended the last step
+        float4* Bn = An + (GBK / 4) * GPA;
+        const bool has_next = k0 + GBK < k_hi;
+        const float4* ap = As4 + half * GPA + wm * 32 + j;
+        const float4* bp = Bs4 + half * GPB + wn * 32 + j;
+        float4 av[2], bv[2];
+        av[0] = ap[0], bv[0] = bp[0];
+#pragma unroll
+        for (int g = 0; g < GBK / 8; ++g) {
+            if (g + 1 < GBK / 8) av[(g + 1) & 1] = ap[(g + 1) * 2 * GPA], bv[(g + 1) & 1] = bp[(g + 1) * 2 * GPB];
+            __builtin_amdgcn_sched_barrier(0);  // keep the next group's reads above this group's MFMAs
+            const float4 a4 = av[g & 1], b4 = bv[g & 1];
+            acc4[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc4[0], 0, 0, 0);
+            acc4[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc4[1], 0, 0, 0);
+            acc4[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc4[2], 0, 0, 0);
+            acc4[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc4[3], 0, 0, 0);
+            if (g >= GBK / 16 && has_next) {  // second half: step t+1 goes to the other stage, two pieces per MFMA group
+#pragma unroll
+                for (int q = 0; q < NPIECE / 4; ++q) commit_piece((g - GBK / 16) * (NPIECE / 4) + q, Rnext, An, Bn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+
+    GemmRegs R0, R1;
+    prefetch(k_lo, R0);
+    prefetch(k_lo + GBK, R1);
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) commit_piece(q, R0, gsm, gsm + (GBK / 4) * GPA);
+    __syncthreads();
+    for (int k0 = k_lo; k0 < k_hi; k0 += 2 * GBK) {
+        step(k0, 0, R0, R1);
+        step(k0 + GBK, 1, R1, R0);
+    }
+    // epilogue.  Split-K: slice 0 carries bias + residual, every slice adds atomically; the QuickGELU' factor is
+    // linear in the sum, so each slice applies it to its own partial.  Loads before stores (one in-order vmcnt).
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    float4 ar[2], br[2];
-    auto prefetch = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = (tid >> 3) + 32 * it, kq = (tid & 7) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + row < p.m && k0 + kq < p.k) v = *reinterpret_cast<const float4*>(p.a + (int64_t)(m0 + row) * p.lda + k0 + kq);
-            ar[it] = v;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TRANS_B) {
-                if (n0 + row < p.n && k0 + kq < p.k) w = *reinterpret_cast<const float4*>(p.b + (int64_t)(n0 + row) * p.ldb + k0 + kq);
-            } else {
-                const int kr = (tid >> 4) + 16 * it, nq = (tid & 15) * 4;
-                if (k0 + kr < p.k && n0 + nq < p.n) w = *reinterpret_cast<const float4*>(p.b + (int64_t)(k0 + kr) * p.ldb + n0 + nq);
-            }
-            br[it] = w;
-        }
-    };
-    auto commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = (tid >> 3) + 32 * it, kq = (tid & 7) * 4;
-            float4 v = ar[it];
-            if (A_GELU) v.x = quick_gelu(v.x), v.y = quick_gelu(v.y), v.z = quick_gelu(v.z), v.w = quick_gelu(v.w);
-            float* d = As + row * GPA + kq;
-            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-            if (TRANS_B) {
-                float* e = Bs + row * GPA + kq;
-                e[0] = br[it].x, e[1] = br[it].y, e[2] = br[it].z, e[3] = br[it].w;
-            } else {
-                const int kr = (tid >> 4) + 16 * it, nq = (tid & 15) * 4;
-                *reinterpret_cast<float4*>(Bs + kr * GBN + nq) = br[it];
-            }
-        }
-    };
-
-    const int k_lo = blockIdx.z * p.k_per;
-    const int k_hi = (k_lo + p.k_per < p.k) ? k_lo + p.k_per : p.k;
-    prefetch(k_lo);
-    for (int k0 = k_lo; k0 < k_hi; k0 += GBK) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (k0 + GBK < k_hi) prefetch(k0 + GBK);
-        const float* ap = As + (wm * 32 + j) * GPA + half;
-        const float* bp = TRANS_B ? Bs + (wn * 32 + j) * GPA + half : Bs + half * GBN + wn * 32 + j;
-#pragma unroll
-        for (int s = 0; s < GBK / 2; ++s) {
-            const float av = ap[2 * s];
-            const float bv = TRANS_B ? bp[2 * s] : bp[2 * s * GBN];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-    }
+    for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+    const bool first = blockIdx.z == 0;
     const int n = n0 + wn * 32 + j;
-    if (n >= p.n) return;
-    const bool first = blockIdx.z == 0;  // split-K: slice 0 carries bias + residual, every slice adds atomically
+    if (m0 + wm * 32 >= p.m || n >= p.n) return;
     const float bs = (p.bias && first) ? p.bias[n] : 0.f;
+    float rs[16], ax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int64_t ci = (int64_t)(m < p.m ? m : 0) * p.ldc + n;
+        rs[r] = (p.residual && first) ? p.residual[ci] : 0.f;
+        ax[r] = p.aux ? p.aux[ci] : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= p.m) continue;
         const int64_t ci = (int64_t)m * p.ldc + n;
-        float v = acc[r] + bs;
-        if (p.residual && first) v += p.residual[ci];
-        if (gridDim.z > 1) {
-            atomicAdd(&p.c[ci], v);
-        } else {
-            if (p.aux) v *= quick_gelu_grad(p.aux[ci]);
-            p.c[ci] = v;
-        }
+        float v = acc[r] + bs + rs[r];
+        if (p.aux) v *= quick_gelu_grad(ax[r]);
+        if (gridDim.z > 1) atomicAdd(&p.c[ci], v);
+        else p.c[ci] = v;
     }
 }
 
@@ -324,12 +423,21 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     // K/2-long dependent MFMA chain: split K over blockIdx.z (fp32 atomics onto a zeroed C) until the grid fills the chip.
     const int64_t tiles = ceil_div(n, GBN) * ceil_div(m, GBM);
     int splits = 1;
-    if (!gelu_grad_aux && ldc == n) {
-        static const int tune_t = getenv("W2E_TUNE_GEMM_T") ? atoi(getenv("W2E_TUNE_GEMM_T")) : 256;
-        static const int tune_k = getenv("W2E_TUNE_GEMM_K") ? atoi(getenv("W2E_TUNE_GEMM_K")) : 256;
-        while (tiles * splits < tune_t && splits < 16 && k / (splits * 2) >= tune_k) splits *= 2;
+    if (ldc == n) {
+        // per workgroup: ~0.9 us per 64-deep K-step (32 MFMAs per wave) + ~2 us of prologue/epilogue; a split adds the
+        // memset launch and the atomics (64 wave-instructions per workgroup at ~50 ns each).  Units: microseconds.
+        static const int tune_s = getenv("W2E_TUNE_GEMM_S") ? atoi(getenv("W2E_TUNE_GEMM_S")) : 0;
+        double best = 0.0;
+        for (int sp = 1; sp <= 16; ++sp) {
+            const int kp = (int)(ceil_div(ceil_div(k, sp), 2 * GBK) * 2 * GBK);
+            if (sp > 1 && ceil_div(k, kp) != sp) continue;
+            const double per_cu = (double)ceil_div(tiles * sp, 256);
+            const double cost = per_cu * ((kp / GBK) * 0.9 + (sp > 1 ? 3.2 : 0.0)) + 2.0 + (sp > 1 ? 3.0 : 0.0);
+            if (sp == 1 || cost < best * 0.97) best = cost, splits = sp;
+        }
+        if (tune_s > 0) splits = tune_s;
     }
-    const int k_per = (int)(ceil_div(ceil_div(k, splits), GBK) * GBK);
+    const int k_per = (int)(ceil_div(ceil_div(k, splits), 2 * GBK) * 2 * GBK);  // an even number of 64-deep steps
     splits = (int)ceil_div(k, k_per);
     if (splits > 1 && hipMemsetAsync(c, 0, sizeof(float) * (size_t)m * n, s) != hipSuccess) {
         set_error("gemm: memset failed");
@@ -337,11 +445,16 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     }
     GemmParams p{a, b, c, m, n, k, lda, ldb, ldc, bias, residual, gelu_grad_aux, k_per};
     dim3 grid((unsigned)ceil_div(n, GBN), (unsigned)ceil_div(m, GBM), (unsigned)splits);
+    constexpr size_t lds = sizeof(float4) * 2 * (GBK / 4) * (GPA + GPB);  // two stages, 99 KB
+    static const bool lds_ok = set_big_lds((const void*)gemm_kernel<true, true>, lds) == 0 &&
+                               set_big_lds((const void*)gemm_kernel<true, false>, lds) == 0 &&
+                               set_big_lds((const void*)gemm_kernel<false, false>, lds) == 0;
+    W2E_REQUIRE(lds_ok, "gemm: cannot enable %zu B of dynamic LDS", lds);
     if (trans_b) {
-        if (a_gelu) gemm_kernel<true, true><<<grid, 256, 0, s>>>(p);
-        else gemm_kernel<true, false><<<grid, 256, 0, s>>>(p);
+        if (a_gelu) gemm_kernel<true, true><<<grid, 256, lds, s>>>(p);
+        else gemm_kernel<true, false><<<grid, 256, lds, s>>>(p);
     } else {
-        gemm_kernel<false, false><<<grid, 256, 0, s>>>(p);
+        gemm_kernel<false, false><<<grid, 256, lds, s>>>(p);
     }
     W2E_LAUNCH_CHECK("gemm");
     return 0;
