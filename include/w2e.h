@@ -101,6 +101,17 @@ int w2e_demod_fwd(const float* s, const float* wsq, float* d, int batch, int cin
 int w2e_demod_bwd(const float* sums, const float* dz, const float* noise_w, const float* bias, const float* d,
                   const float* s, const float* wsq, float* gs, float* gd, int batch, int cin, int cout, void* stream);
 
+/* All style modulations of one generator pass in one launch (model.py:211, `style = self.modulation(style)` in each of
+ * the 26 ModulatedConv2d): every layer's EqualLinear(style_dim, cin_l) -- weight*scale and bias*lr_mul, model.py:151-158
+ * -- stacked row-wise into w [rows, dim] and bias [rows] (NULL = none).  meta [rows][4] (int32) per stacked row =
+ * (W+ index of the layer, rows before the layer, cin_l, row inside the layer); every cin_l is a multiple of 32.
+ *   out[rows_before_l*batch + b*cin_l + c] = latent[b, widx_l, :] . w[row, :] + bias[row]     (layer blocks [batch, cin_l])
+ * bwd: glatent [batch, n_latent, dim] = the adjoint w.r.t. latent (zeroed inside; layers sharing a W+ index add up). */
+int w2e_style_affine_fwd(const float* latent, const float* w, const float* bias, const int* meta, float* out, int batch,
+                         int n_latent, int dim, int rows, void* stream);
+int w2e_style_affine_bwd(const float* gout, const float* w, const int* meta, float* glatent, int batch, int n_latent,
+                         int dim, int rows, void* stream);
+
 /* ---- K1r  ToRGB: modulated 1x1 conv (no demod) + bias + upsampled skip  (model.py:343-362) --
  * wmod [B,3,cin] = scale*W[c,i]*s[b,i] (tiny, built by the host);  skip [B,3,h/2,w/2] or NULL is
  * up-sampled x2 with the 4x4 kernel `upk` (Upsample, model.py:31-49: up=2, pad (2,1)) and added. */

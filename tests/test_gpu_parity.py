@@ -431,3 +431,34 @@ def test_modconv_full_size_properties(cin, cout, h, up):
         got = y[:1, :, c0:c0 + 8, c0:c0 + 8]
         ref = ref[:, :, halo:halo + 8, halo:halo + 8]
     assert_close(got, ref, FWD_TOL, "crop vs oracle")
+
+
+def test_batched_style_affines_match_per_layer_path():
+    """w2e_style_affine_fwd/bwd (all 26 modulation EqualLinears in one launch) against the per-layer EqualLinear path:
+    styles, image and the W+ gradient."""
+    g = _gen(64)
+    for p in g.parameters():
+        p.requires_grad_(False)
+    w = cu(seeded.wplus_latents(3, g.n_latent))
+
+    def run(batched):
+        wl = w.clone().requires_grad_(True)
+        if not batched:
+            g._batched_styles = lambda latent, plan: None
+        try:
+            img, _, styles = g([wl], input_is_latent=True, randomize_noise=False, return_latents=True)
+        finally:
+            if not batched:
+                del g._batched_styles
+        gy = cu(seeded.tensor("style.gy", tuple(img.shape)))
+        (gw,) = torch.autograd.grad(img, wl, gy)
+        return img, styles, gw
+
+    img_a, st_a, gw_a = run(True)
+    img_b, st_b, gw_b = run(False)
+    assert len(st_a) == len(st_b)
+    for a, b in zip(st_a, st_b):
+        assert a.shape == b.shape
+        assert_close(a, b, 1e-5, "style")
+    assert_close(img_a, img_b, 1e-4, "image")
+    assert_grad_close(gw_a, gw_b, "w+ grad")

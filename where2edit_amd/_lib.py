@@ -24,6 +24,8 @@ _PROTOS = {
     "w2e_modconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "w2e_demod_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "w2e_demod_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "w2e_style_affine_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_style_affine_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_torgb_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_torgb_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_clip_preproc_fwd": (_I, [_P, _P, _L, _I, _P]),

@@ -344,6 +344,59 @@ __global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict_
     gs[(int64_t)b * Cin + i] -= s[(int64_t)b * Cin + i] * acc;
 }
 
+
+// All modulation affines of one generator pass in one launch (model.py:211 `style = self.modulation(style)`, 26 times
+// per forward): out[l][b][c] = latent[b, widx_l, :] . W_l[c, :] + bias_l[c], with every layer's (scale*W, lr_mul*b)
+// stacked row-wise into w [R, D], bias [R].  meta[r] = (W+ index, rows before this layer, layer width, row in layer).
+// One wave per stacked row: the weight row is read once and dotted with the row's latent of every batch element.
+__global__ __launch_bounds__(256) void style_affine_fwd_kernel(const float* __restrict__ latent, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const int4* __restrict__ meta,
+                                                               float* __restrict__ out, int B, int L, int D, int R) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int4 m = meta[r];
+    const float bs = bias ? bias[r] : 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* lat = latent + ((int64_t)b * L + m.x) * D;
+        float acc = 0.f;
+        for (int k = lane * 4; k < D; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)r * D + k);
+            const float4 lv = *reinterpret_cast<const float4*>(lat + k);
+            acc += wv.x * lv.x + wv.y * lv.y + wv.z * lv.z + wv.w * lv.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[(int64_t)m.y * B + (int64_t)b * m.z + m.w] = acc + bs;
+    }
+}
+
+// glatent[b, widx_l, k] += sum_c gout[l][b][c] * W_l[c, k].  Block = (32 stacked rows -- layer widths are multiples of
+// 32, so one W+ index per block --, b); threads over k (coalesced weight rows); one atomic per (block, k).
+__global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ w,
+                                                               const int4* __restrict__ meta, float* __restrict__ glatent,
+                                                               int B, int L, int D, int R) {
+    __shared__ float g[32];
+    const int r0 = blockIdx.x * 32, b = blockIdx.y;
+    if (threadIdx.x < 32) {
+        const int r = r0 + threadIdx.x;
+        float v = 0.f;
+        if (r < R) {
+            const int4 m = meta[r];
+            v = gout[(int64_t)m.y * B + (int64_t)b * m.z + m.w];
+        }
+        g[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const int widx = meta[r0].x;
+    const int nr = (R - r0 < 32) ? R - r0 : 32;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < nr; ++i) acc += g[i] * w[(int64_t)(r0 + i) * D + k];
+        atomicAdd(&glatent[((int64_t)b * L + widx) * D + k], acc);
+    }
+}
+
 }  // namespace w2e
 
 using namespace w2e;
@@ -498,5 +551,33 @@ int w2e_id_preproc_bwd(const float* gout, float* gimg, int64_t planes, int size,
     W2E_LAUNCH_CHECK("id_preproc_bwd");
     return 0;
 }
+
+int w2e_style_affine_fwd(const float* latent, const float* w, const float* bias, const int* meta, float* out, int batch,
+                         int n_latent, int dim, int rows, void* stream) {
+    W2E_REQUIRE(latent && w && meta && out, "style_affine_fwd: null tensor");
+    W2E_REQUIRE(batch >= 0 && n_latent > 0 && dim > 0 && (dim & 3) == 0 && rows > 0, "style_affine_fwd: bad dims");
+    if (batch == 0) return 0;
+    style_affine_fwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(
+        latent, w, bias, reinterpret_cast<const int4*>(meta), out, batch, n_latent, dim, rows);
+    W2E_LAUNCH_CHECK("style_affine_fwd");
+    return 0;
+}
+
+int w2e_style_affine_bwd(const float* gout, const float* w, const int* meta, float* glatent, int batch, int n_latent,
+                         int dim, int rows, void* stream) {
+    W2E_REQUIRE(gout && w && meta && glatent, "style_affine_bwd: null tensor");
+    W2E_REQUIRE(batch >= 0 && batch < 65536 && n_latent > 0 && dim > 0 && rows > 0, "style_affine_bwd: bad dims");
+    if (batch == 0) return 0;
+    if (hipMemsetAsync(glatent, 0, sizeof(float) * (size_t)batch * n_latent * dim, (hipStream_t)stream) != hipSuccess) {
+        set_error("style_affine_bwd: memset failed");
+        return 2;
+    }
+    dim3 grid((unsigned)ceil_div(rows, 32), (unsigned)batch);
+    style_affine_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gout, w, reinterpret_cast<const int4*>(meta), glatent, batch,
+                                                                 n_latent, dim, rows);
+    W2E_LAUNCH_CHECK("style_affine_bwd");
+    return 0;
+}
+
 
 }  // extern "C"

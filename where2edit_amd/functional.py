@@ -246,6 +246,49 @@ def modconv_down_plain(x, s, d, wp_f, h, w):
     return y
 
 
+# ------------------------------------------------------------------------------------------ style affines
+class _StyleAffineAll(torch.autograd.Function):
+    """Every `style = self.modulation(style)` of one generator pass (model.py:211, 26 EqualLinear calls) in one launch.
+    pack = (w [R,D] = stacked weight*scale, bias [R] = stacked bias*lr_mul, meta int32 [R,4], widths): see w2e.h.
+    Returns one [B, cin_l] tensor per layer; differentiable in the latent only (the decoder is frozen on this path)."""
+
+    @staticmethod
+    def forward(ctx, latent, pack):
+        import ctypes
+        latent = _c(latent)
+        b, n_latent, dim = latent.shape
+        w, bias, meta, widths = pack
+        rows = w.shape[0]
+        out = torch.empty(b * rows, device=latent.device, dtype=torch.float32)
+        call("w2e_style_affine_fwd", ptr(latent), ptr(w), ptr(bias), ctypes.c_void_p(meta.data_ptr()), ptr(out), b, n_latent,
+             dim, rows, stream_ptr())
+        ctx.pack = pack
+        ctx.geom = (b, n_latent, dim)
+        outs, off = [], 0
+        for cw in widths:
+            outs.append(out[off * b:(off + cw) * b].view(b, cw))
+            off += cw
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        import ctypes
+        b, n_latent, dim = ctx.geom
+        w, bias, meta, widths = ctx.pack
+        parts = [(g.reshape(-1) if g is not None else torch.zeros(b * cw, device=w.device, dtype=torch.float32))
+                 for g, cw in zip(gs, widths)]
+        flat = torch.cat(parts)
+        glat = torch.empty((b, n_latent, dim), device=w.device, dtype=torch.float32)
+        call("w2e_style_affine_bwd", ptr(flat), ptr(w), ctypes.c_void_p(meta.data_ptr()), ptr(glat), b, n_latent, dim,
+             w.shape[0], stream_ptr())
+        return glat, None
+
+
+def style_affine_all(latent, pack):
+    return _StyleAffineAll.apply(latent, pack)
+
+
 # ------------------------------------------------------------------------------------------ K1r
 class _ToRGB(torch.autograd.Function):
     @staticmethod
@@ -271,7 +314,7 @@ class _ToRGB(torch.autograd.Function):
         gx = torch.empty_like(x)
         gw = torch.empty_like(wmod)
         call("w2e_torgb_bwd", ptr(x), ptr(wmod), ptr(gy), ptr(gx), ptr(gw), b, cin, h, w, stream_ptr())
-        gb = gy.sum((0, 2, 3)).reshape(bias_shape) if has_bias else None
+        gb = gy.sum((0, 2, 3)).reshape(bias_shape) if (has_bias and ctx.needs_input_grad[2]) else None
         gskip = None
         if has_skip:  # adjoint of Upsample(up=2, pad=(2,1)): down=2, un-flipped taps, leading pad 4-1-2
             gskip = _upfirdn2d_raw(gy, upk, h // 2, w // 2, 1, 2, 1, 1, False)

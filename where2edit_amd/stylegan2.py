@@ -397,12 +397,49 @@ class Generator(nn.Module):
             i += 2
         return plan
 
+    def _style_pack(self, plan):
+        """All modulation affines stacked for w2e_style_affine_* (rebuilt when any of their parameters changes)."""
+        mods = [m.conv.modulation for m, _, _, _ in plan]
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        if getattr(self, "_style_pack_key", None) != key:
+            with torch.no_grad():
+                w = torch.cat([m.weight.detach().float() * m.scale for m in mods]).contiguous()
+                b = torch.cat([m.bias.detach().float() * m.lr_mul for m in mods]).contiguous()
+                meta, off = [], 0
+                for (_, _, widx, _), m in zip(plan, mods):
+                    cw = m.weight.shape[0]
+                    meta.append(torch.stack([torch.full((cw,), widx), torch.full((cw,), off), torch.full((cw,), cw),
+                                             torch.arange(cw)], 1))
+                    off += cw
+                meta = torch.cat(meta).to(device=w.device, dtype=torch.int32).contiguous()
+            self._style_pack_val = (w, b, meta, [m.weight.shape[0] for m in mods])
+            self._style_pack_key = key
+        return self._style_pack_val
+
+    def _batched_styles(self, latent, plan):
+        """The 26 per-layer style vectors from one launch, when the modulation layers are frozen (they are on every
+        path of SURVEY 8: the decoder is never optimised) and the input is a W+ tensor; None = per-layer path."""
+        if not (torch.is_tensor(latent) and latent.ndim == 3 and latent.is_cuda):
+            return None
+        mods = [m.conv.modulation for m, _, _, _ in plan]
+        if any(m.bias is None or m.weight.shape[0] % 32 for m in mods):
+            return None
+        if torch.is_grad_enabled() and any(m.weight.requires_grad or m.bias.requires_grad for m in mods):
+            return None
+        return K.style_affine_all(latent, self._style_pack(plan))
+
     def _synthesis(self, latent, noise, input_is_stylespace, on_layer=None):
         batch_ref = latent[0] if input_is_stylespace else latent
         out = self.input(batch_ref)
         skip = None
         style_vector = []
-        for n, (mod, is_rgb, widx, nidx) in enumerate(self._layers()):
+        plan = self._layers()
+        batched = None if input_is_stylespace else self._batched_styles(latent, plan)
+        if batched is not None:
+            batch = latent.shape[0]
+            latent = [s.view(batch, 1, s.shape[1], 1, 1) for s in batched]
+            input_is_stylespace = True
+        for n, (mod, is_rgb, widx, nidx) in enumerate(plan):
             sty = latent[n] if input_is_stylespace else latent[:, widx]
             if is_rgb:
                 skip, s = mod(out, sty, skip, input_is_stylespace=input_is_stylespace)
