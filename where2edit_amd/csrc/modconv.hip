@@ -60,6 +60,13 @@ struct ConvParams {
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
 
+// Internal variant of W2E_CONV_UP chosen by the host per layer: a workgroup computes ALL FOUR output phases of a
+// (4x smaller) input-pixel tile from one staged patch and all 9 taps -- the NPB accumulator columns of a wave are
+// 4 phases x NPB/4 pixel blocks.  The per-phase form stages the activation patch once per phase (4 patches per 9 taps);
+// this one stages it once, which wins where the patch, not the weights, dominates staging (few channels, many pixels).
+constexpr int CONV_UPALL = 3;
+__host__ __device__ constexpr bool is_up(int mode) { return mode == W2E_CONV_UP || mode == CONV_UPALL; }
+
 // Upper bound of ceil(patch / threads) for a tile of `tm` pixels (the host refuses geometries beyond it).
 __host__ __device__ constexpr int max_patch_slots(int mode, int tm, int nt) {
     return mode == W2E_CONV_DOWN ? (nt == 512 ? (tm >= 1024 ? 9 : 5) : (tm >= 512 ? 9 : (tm >= 256 ? 5 : (tm >= 128 ? 3 : (tm >= 64 ? 2 : 1)))))
@@ -92,6 +99,37 @@ struct Chunk {
 template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4* ws, const float4* xs, int a_base,
                                            const int (&base)[NPB], int pw, int plane) {
+    using T = Taps<MODE, PY, PX>;
+    if constexpr (MODE == CONV_UPALL) {
+        constexpr int NPP = NPB / 4;  // pixel blocks per phase
+#pragma unroll
+        for (int sub = 0; sub < KCP / 8; ++sub) {
+            float4 bv[4][NPP];  // the 4 patch offsets (-(a>>1), -(b>>1)) the 9 taps read
+#pragma unroll
+            for (int off = 0; off < 4; ++off)
+#pragma unroll
+                for (int pb = 0; pb < NPP; ++pb) bv[off][pb] = xs[base[pb] + sub * 2 * plane - (off >> 1) * pw - (off & 1)];
+#pragma unroll
+            for (int slot = 0; slot < 9; ++slot) {
+                const int ta = slot / 3, tb = slot % 3;
+                const int phase = (ta & 1) * 2 + (tb & 1), off = (ta >> 1) * 2 + (tb >> 1);
+                float4 av[NOB];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (sub * 9 + slot) * 2 * TN + ob * 32];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int pb = 0; pb < NPP; ++pb) {
+                        f32x16& a = acc[ob][phase * NPP + pb];
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].x, bv[off][pb].x, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].y, bv[off][pb].y, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].z, bv[off][pb].z, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].w, bv[off][pb].w, a, 0, 0, 0);
+                    }
+            }
+        }
+        return;
+    }
     using T = Taps<MODE, PY, PX>;
 #pragma unroll
     for (int sub = 0; sub < KCP / 8; ++sub) {
@@ -210,7 +248,8 @@ template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
 __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
     constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
     constexpr int TN = 32 * NOB * WO;
-    constexpr int MAXX = max_patch_slots(MODE, 32 * NPB * WP, NT);  // activation-patch elements per thread (x KC channels)
+    constexpr int NPX = (MODE == CONV_UPALL) ? NPB / 4 : NPB;  // pixel blocks per wave (UPALL: NPB = 4 phases x NPX)
+    constexpr int MAXX = max_patch_slots(MODE == CONV_UPALL ? W2E_CONV_UP : MODE, 32 * NPX * WP, NT);  // activation-patch elements per thread (x KC channels)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WS_FLOATS = (MODE == W2E_CONV_UP ? 32 : KC * 9) * TN;  // every phase stages KCP*NTAPS <= 32 (k,tap) rows
     float4* ws = reinterpret_cast<float4*>(smem);              // [KCP/8][NTAPS][2][TN] float4
@@ -221,7 +260,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int wo = wave / WP, wpx = wave % WP;
 
     int bid = blockIdx.x;
-    if (MODE == W2E_CONV_UP) {
+    if (is_up(MODE)) {
         if (bid < p.border_wgs) {  // uniform per workgroup
             if (p.N >= 64) upconv_border<64, NT>(p, smem, bid);
             else upconv_border<32, NT>(p, smem, bid);
@@ -250,15 +289,15 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     // epilogue instead of being kept live across the MFMA loop)
     int base[NPB];
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-        const int m = (wpx * NPB + pb) * 32 + j;
+    for (int pb = 0; pb < NPX; ++pb) {
+        const int m = (wpx * NPX + pb) * 32 + j;
         const int ly = m >> p.tw_log2, lx = m & (p.tw - 1);
         const bool ok = ly < p.th && r0 + ly < p.H && c0 + lx < p.W;
         int off;
         if (MODE == W2E_CONV_SAME) off = ly * p.pw + lx;            // patch origin (r0-1, c0-1); tap (a,b): +a*pw+b
-        else if (MODE == W2E_CONV_UP) off = (ly + 1) * p.pw + lx + 1;  // same origin; tap: -(a>>1)*pw-(b>>1)
+        else if (is_up(MODE)) off = (ly + 1) * p.pw + lx + 1;  // same origin; tap: -(a>>1)*pw-(b>>1)
         else off = 2 * ly * p.pw + 2 * lx;                          // origin (2r0, 2c0); tap: +a*pw+b
-        if (!ok) off = (MODE == W2E_CONV_UP) ? p.pw + 1 : 0;
+        if (!ok) off = is_up(MODE) ? p.pw + 1 : 0;
         base[pb] = half * p.plane + off;
     }
 
@@ -379,7 +418,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     bool valid[NPB];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
-        const int m = (wpx * NPB + pb) * 32 + j;
+        const int m = (wpx * NPX + pb % NPX) * 32 + j;
         const int ly = m >> p.tw_log2, lx = m & (p.tw - 1);
         gy[pb] = r0 + ly;
         gx[pb] = c0 + lx;
@@ -393,11 +432,12 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
         // UP writes its phase plane of the phase-planar image [4][H+1][W+1]: unit-stride rows
-        if (MODE == W2E_CONV_UP) pix[pb] = (phase * (p.H + 1) + gy[pb]) * ((p.W + 4) & ~3) + gx[pb];
+        const int ph_pb = (MODE == CONV_UPALL) ? pb / NPX : phase;
+        if (is_up(MODE)) pix[pb] = (ph_pb * (p.H + 1) + gy[pb]) * ((p.W + 4) & ~3) + gx[pb];
         else pix[pb] = gy[pb] * p.out_w + gx[pb];
         nz[pb] = (EPI == EPI_ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
     }
-    const int out_plane = (MODE == W2E_CONV_UP) ? 4 * (p.H + 1) * ((p.W + 4) & ~3) : p.out_h * p.out_w;
+    const int out_plane = is_up(MODE) ? 4 * (p.H + 1) * ((p.W + 4) & ~3) : p.out_h * p.out_w;
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         float os[16], bs[16];
@@ -499,26 +539,40 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
 
 template <int MODE, int EPI, int KC>
 static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
-    switch (cfg) {
-        case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC>(p, grid, lds, s); return true;
-        case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC>(p, grid, lds, s); return true;
-        case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC>(p, grid, lds, s); return true;
-        case 3: launch_cfg<MODE, EPI, 2, 2, 2, 2, KC>(p, grid, lds, s); return true;
-        case 4: launch_cfg<MODE, EPI, 1, 4, 2, 2, KC>(p, grid, lds, s); return true;
-        case 5: launch_cfg<MODE, EPI, 1, 2, 2, 2, KC>(p, grid, lds, s); return true;
-        case 6: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
-        case 7: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
-        case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC>(p, grid, lds, s); return true;
-        case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC>(p, grid, lds, s); return true;
-        case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC>(p, grid, lds, s); return true;
+    if constexpr (MODE == CONV_UPALL) {  // accumulator columns = 4 phases x NPB/4 pixel blocks
+        switch (cfg) {
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC>(p, grid, lds, s); return true;
+            case 4: launch_cfg<MODE, EPI, 1, 4, 2, 2, KC>(p, grid, lds, s); return true;
+            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC>(p, grid, lds, s); return true;
+            case 11: launch_cfg<MODE, EPI, 1, 8, 1, 8, KC>(p, grid, lds, s); return true;
+        }
+        return false;
+    } else {
+        switch (cfg) {
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC>(p, grid, lds, s); return true;
+            case 3: launch_cfg<MODE, EPI, 2, 2, 2, 2, KC>(p, grid, lds, s); return true;
+            case 4: launch_cfg<MODE, EPI, 1, 4, 2, 2, KC>(p, grid, lds, s); return true;
+            case 5: launch_cfg<MODE, EPI, 1, 2, 2, 2, KC>(p, grid, lds, s); return true;
+            case 6: launch_cfg<MODE, EPI, 1, 1, 2, 2, KC>(p, grid, lds, s); return true;
+            case 7: launch_cfg<MODE, EPI, 1, 1, 4, 1, KC>(p, grid, lds, s); return true;
+            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC>(p, grid, lds, s); return true;
+            case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC>(p, grid, lds, s); return true;
+            case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC>(p, grid, lds, s); return true;
+        }
+        return false;
     }
-    return false;
 }
 
 static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},               // 512 threads, 1 workgroup / CU
                                    {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4},  // 256 threads
-                                   {2, 2, 2, 4}, {2, 2, 1, 8}};  // 512 threads, 4 accumulators per wave (register headroom)
-static const int kNumCfg = 11;
+                                   {2, 2, 2, 4}, {2, 2, 1, 8},  // 512 threads, 4 accumulators per wave (register headroom)
+                                   {1, 8, 1, 8}};               // all-phase UP only: 32 channels x (4 phases x 2 pixel blocks)
+static const int kNumCfg = 11;  // configurations of the per-phase / SAME / DOWN kernels
+static const int kNumCfgAll = 12;
 
 static int next_pow2(int v) {
     int r = 1;
@@ -593,32 +647,72 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
         const double waves_per_simd = nt / 256.0;
         const double unit = (double)cfgs[c].nob * cfgs[c].npb * waves_per_simd * (k_ch / 2.0) * 64.0;  // one tap
-        const double t_stage = (double)ceil_div(k_ch, kc) * 1200.0;
+        const double t_stage0 = (double)ceil_div(k_ch, kc) * 1200.0;
         // split-K (low resolutions: a handful of tiles, each a K*9/2-long dependent MFMA chain): S slices of the
         // channel range per tile, summed with fp32 atomics onto a zeroed output
         for (int sp = 1; sp <= 32; sp *= 2) {
             if (sp > 1 && (k_ch / sp < 2 * kc_max || (up ? 4.0 : 1.0) * tiles * (sp / 2) >= 256.0)) break;
             double cost;
+            // a lone 256-thread workgroup on a CU has nobody to hide its staging behind (1 wave per SIMD)
+            const double t_stage = t_stage0 * ((nt == 256 && (up ? 4.0 : 1.0) * tiles * sp <= 256.0) ? 2.5 : 1.0);
             if (up) {  // 4 phases with 4/2/2/1 taps, heaviest dispatched first
                 const double per_cu = ceil(4.0 * tiles * sp / 256.0) / 4.0;  // tile-slices (sets of 4 phases) per CU
                 cost = per_cu * ((9.0 * unit + 4.0 * t_stage) / sp + 16000.0) + (4.0 * tiles * sp < 1024.0 ? 1.75 * unit / sp : 0.0);
             } else {
                 cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + t_stage) / sp + 4000.0);  // + prologue/epilogue per workgroup
             }
-            if (sp > 1) cost = cost * 1.06 + 8000.0;  // memset + atomics + (with act) the separate bias/act pass
-            if (cfgs[c].nob * cfgs[c].npb >= 8 && nt == 512 && mode != W2E_CONV_UP) cost *= 1.0;
+            if (sp > 1) {  // memset + (with act) the separate bias/act pass + the fp32 atomics: ~120 cycles per 256-B
+                           // wave-instruction per CU (MI355X_MICROARCH.md, global float atomics)
+                const double wgs_per_cu = ceil((up ? 4.0 : 1.0) * tiles * sp / 256.0);
+                cost = cost * 1.06 + 8000.0 + wgs_per_cu * ((double)tn * tm / 64.0) * 120.0;
+            }
             if (best < 0 || cost < best_cost * 0.995) best = c, best_cost = cost, best_splits = sp;
+        }
+    }
+    // UP: the all-phase form (one staged patch, 9 taps, 4 phases x NPB/4 pixel blocks per wave) as the alternative
+    bool use_all = false;
+    if (up) {
+        static const int kAll[] = {0, 1, 2, 4, 8, 11};
+        static const int tune_all = getenv("W2E_TUNE_UPALL") ? atoi(getenv("W2E_TUNE_UPALL")) : -1;  // 0 never, 1 always
+        int best_a = -1, best_a_splits = 1;
+        double best_a_cost = 0.0;
+        for (int ci = 0; ci < 6 && tune_all != 0; ++ci) {
+            const int c = kAll[ci];
+            const int tn = 32 * cfgs[c].nob * cfgs[c].wo, tm = 32 * (cfgs[c].npb / 4) * cfgs[c].wp;
+            const int tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
+            const int th = tm / tw;
+            if (th < 1) continue;
+            const int ph = th + 1, pw = tw + 1;
+            const int nt = 64 * cfgs[c].wo * cfgs[c].wp;
+            if (sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw) > 150 * 1024) continue;
+            if (ph * pw > nt * max_patch_slots(W2E_CONV_UP, tm, nt)) continue;
+            const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
+            const double unit = (double)cfgs[c].nob * (cfgs[c].npb / 4) * (nt / 256.0) * (k_ch / 2.0) * 64.0;  // one tap
+            const double t_stage = (double)ceil_div(k_ch, kc) * 1200.0;
+            for (int sp = 1; sp <= 32; sp *= 2) {
+                if (sp > 1 && (k_ch / sp < 2 * kc || tiles * (sp / 2) >= 256.0)) break;
+                // a split adds the memset and the fp32 atomics: ~120 cycles per 256-B wave-instruction per CU
+                const double atomics = sp > 1 ? (double)tn * tm * 4.0 / 64.0 * 120.0 : 0.0;
+                double cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + t_stage) / sp + 6000.0 + atomics);  // 4 output planes per tile
+                if (sp > 1) cost = cost * 1.06 + 8000.0;
+                if (best_a < 0 || cost < best_a_cost * 0.995) best_a = c, best_a_cost = cost, best_a_splits = sp;
+            }
+        }
+        // measured (tools/layer_bench.py, batch 4): the all-phase form wins from 16x16 inputs up (10-28 %), the per-phase
+        // form below (a handful of tiles: it has 4x the workgroups to spread over the chip)
+        if (best_a >= 0 && (tune_all == 1 || best < 0 || (tune_all < 0 && (int64_t)h * w >= 256))) {
+            use_all = true, best = best_a, best_splits = best_a_splits, best_cost = best_a_cost;
         }
     }
     if (const char* sk = getenv("W2E_TUNE_SKIP")) p.tune_skip = atoi(sk);
     if (const char* force = getenv("W2E_TUNE_CFG")) {  // tuning aid (tools/layer_bench.py): "<cfg>[,<splits>]"
         int fc = -1, fs = 1;
-        if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < ncfg) best = fc, best_splits = fs > 0 ? fs : 1;
+        if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < (use_all ? kNumCfgAll : ncfg)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
-    if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "modconv mode %d K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, k_ch, n_ch, h, w, batch, best, best_splits);
+    if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
-    const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * cfg.npb * cfg.wp;
+    const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * (use_all ? cfg.npb / 4 : cfg.npb) * cfg.wp;
     p.tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
     p.th = tm / p.tw;
     p.tw_log2 = 0;
@@ -631,18 +725,19 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     p.pw_magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)p.pw + 1);
     W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
     const int nt_best = 64 * cfg.wo * cfg.wp;
-    const int kdeep_best = (up && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
-    size_t lds = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
-                    : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
+    const int kdeep_best = (up && !use_all && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
+    size_t lds = (up && !use_all) ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
+                                  : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
     W2E_REQUIRE(lds <= 150 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
-    p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), kc_max) * kc_max);
+    const int k_gran = use_all ? kc : kc_max;
+    p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), k_gran) * k_gran);
     p.splits = (int)ceil_div(k_ch, p.k_per);
     if (up) {
         p.groups_row = (int)ceil_div(2 * w + 1, 8), p.groups_col = (int)ceil_div(2 * h, 8);
         p.border_wgs = batch * (p.groups_row + p.groups_col) * (int)ceil_div(n_ch, n_ch >= 64 ? 64 : 32);
     }
-    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * (up ? 4 : 1) * p.splits + p.border_wgs;
+    const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
     if (p.splits > 1 &&
@@ -656,7 +751,8 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         else if (dot_with) ok = launch_mode<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
         else ok = launch_mode<W2E_CONV_SAME, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
     } else if (up) {
-        ok = launch_mode<W2E_CONV_UP, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+        if (use_all) ok = launch_mode<CONV_UPALL, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+        else ok = launch_mode<W2E_CONV_UP, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
     } else {
         if (dot_with) ok = launch_mode<W2E_CONV_DOWN, EPI_DOT, 8>(best, p, (int)grid, lds, s);
         else ok = launch_mode<W2E_CONV_DOWN, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
