@@ -291,32 +291,76 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------ attention
-constexpr int HD = 64, HP = 65, LMAX = 64;
+// One workgroup per (batch, head); L <= 64 tokens, head dim 64.  Everything lives in LDS with 68-float rows (16-B
+// aligned, consecutive rows shifted by 16 B: conflict-free ds_read_b128) and every contraction is register-tiled
+// over float4s -- 16 FMAs per 5 LDS reads instead of 1 per 2, which is what these LDS-bound loops are limited by.
+constexpr int HD = 64, LMAX = 64, HS = 68;
 
-// qkv [B, L, 3, H, 64] -> LDS q[L][64], k[L][65], v[L][65]
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4 v) {
+    acc.x += s * v.x, acc.y += s * v.y, acc.z += s * v.z, acc.w += s * v.w;
+}
+
+// zero `n4` float4s of LDS (rows >= L of every operand must read as zero: the tiled loops run to a multiple of 4)
+__device__ __forceinline__ void lds_zero(float* base, int n4) {
+    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(base)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// qkv [B, L, 3, H, 64] -> LDS q, k, v as [L][HS]
 __device__ __forceinline__ void load_qkv(const float* qkv, int b, int h, int L, int H, float* q, float* k, float* v) {
-    for (int e = threadIdx.x; e < L * HD; e += 256) {
-        const int t = e >> 6, d = e & 63;
+    for (int e = threadIdx.x; e < L * 16; e += 256) {
+        const int t = e >> 4, d = (e & 15) * 4;
         const float* src = qkv + (((int64_t)b * L + t) * 3 * H + h) * HD + d;
-        q[t * HD + d] = src[0];
-        k[t * HP + d] = src[(int64_t)H * HD];
-        v[t * HP + d] = src[(int64_t)2 * H * HD];
+        *reinterpret_cast<float4*>(q + t * HS + d) = *reinterpret_cast<const float4*>(src);
+        *reinterpret_cast<float4*>(k + t * HS + d) = *reinterpret_cast<const float4*>(src + (int64_t)H * HD);
+        *reinterpret_cast<float4*>(v + t * HS + d) = *reinterpret_cast<const float4*>(src + (int64_t)2 * H * HD);
     }
 }
 
-// p[i][j] = softmax_j(q_i . k_j / 8)
-__device__ __forceinline__ void softmax_probs(const float* q, const float* k, float* p, int L) {
-    const int LP = L + 1;
-    for (int e = threadIdx.x; e < L * L; e += 256) {
-        const int i = e / L, jj = e - i * L;
-        float s = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < HD; ++d) s += q[i * HD + d] * k[jj * HP + d];
-        p[i * LP + jj] = s * 0.125f;
+// out[i][j] = scale * a_i . b_j for i < L, j < roundup4(L)   (a, b, out: [.][HS])
+__device__ __forceinline__ void rows_dot_rows(const float* a, const float* b, float* out, int L, float scale) {
+    const int L4 = (L + 3) >> 2;
+    for (int e = threadIdx.x; e < L * L4; e += 256) {
+        const int i = e / L4, j = (e - i * L4) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int d = 0; d < HD; d += 4) {
+            const float4 av = *reinterpret_cast<const float4*>(a + i * HS + d);
+            s.x += dot4(av, *reinterpret_cast<const float4*>(b + (j + 0) * HS + d));
+            s.y += dot4(av, *reinterpret_cast<const float4*>(b + (j + 1) * HS + d));
+            s.z += dot4(av, *reinterpret_cast<const float4*>(b + (j + 2) * HS + d));
+            s.w += dot4(av, *reinterpret_cast<const float4*>(b + (j + 3) * HS + d));
+        }
+        *reinterpret_cast<float4*>(out + i * HS + j) = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
     }
+}
+
+// acc[d..d+3] = sum_u w[t][u] * m[u][d..d+3]  (row weights)  or  sum_u w[u][t] * m[u][d..d+3]  (column weights)
+template <bool COLUMN>
+__device__ __forceinline__ float4 weighted_rows(const float* w, const float* m, int t, int d, int L) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < L; u += 4) {  // rows >= L of m are zero
+        float w0, w1, w2, w3;
+        if (COLUMN) {
+            w0 = w[(u + 0) * HS + t], w1 = w[(u + 1) * HS + t], w2 = w[(u + 2) * HS + t], w3 = w[(u + 3) * HS + t];
+        } else {
+            const float4 wv = *reinterpret_cast<const float4*>(w + t * HS + u);
+            w0 = wv.x, w1 = wv.y, w2 = wv.z, w3 = wv.w;
+        }
+        fma4(acc, w0, *reinterpret_cast<const float4*>(m + (u + 0) * HS + d));
+        fma4(acc, w1, *reinterpret_cast<const float4*>(m + (u + 1) * HS + d));
+        fma4(acc, w2, *reinterpret_cast<const float4*>(m + (u + 2) * HS + d));
+        fma4(acc, w3, *reinterpret_cast<const float4*>(m + (u + 3) * HS + d));
+    }
+    return acc;
+}
+
+// p[i][j] = softmax_j(q_i . k_j / 8); columns L .. roundup4(L)-1 are set to 0
+__device__ __forceinline__ void softmax_probs(const float* q, const float* k, float* p, int L) {
+    rows_dot_rows(q, k, p, L, 0.125f);
     __syncthreads();
     if (threadIdx.x < L) {
-        float* row = p + threadIdx.x * LP;
+        float* row = p + threadIdx.x * HS;
         float mx = row[0];
         for (int jj = 1; jj < L; ++jj) mx = fmaxf(mx, row[jj]);
         float sum = 0.f;
@@ -327,6 +371,7 @@ __device__ __forceinline__ void softmax_probs(const float* q, const float* k, fl
         }
         const float inv = 1.f / sum;
         for (int jj = 0; jj < L; ++jj) row[jj] *= inv;
+        for (int jj = L; jj < ((L + 3) & ~3); ++jj) row[jj] = 0.f;
     }
     __syncthreads();
 }
@@ -334,19 +379,19 @@ __device__ __forceinline__ void softmax_probs(const float* q, const float* k, fl
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* q = smem;
-    float* k = q + LMAX * HD;
-    float* v = k + LMAX * HP;
-    float* p = v + LMAX * HP;
+    float* k = q + LMAX * HS;
+    float* v = k + LMAX * HS;
+    float* p = v + LMAX * HS;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
+    lds_zero(smem, 4 * LMAX * HS / 4);
+    __syncthreads();
     load_qkv(qkv, b, h, L, H, q, k, v);
     __syncthreads();
     softmax_probs(q, k, p, L);
-    const int LP = L + 1;
-    for (int e = threadIdx.x; e < L * HD; e += 256) {
-        const int i = e >> 6, d = e & 63;
-        float s = 0.f;
-        for (int jj = 0; jj < L; ++jj) s += p[i * LP + jj] * v[jj * HP + d];
-        out[(((int64_t)b * L + i) * H + h) * HD + d] = s;
+    for (int e = threadIdx.x; e < L * 16; e += 256) {
+        const int i = e >> 4, d = (e & 15) * 4;
+        const float4 o = weighted_rows<false>(p, v, i, d, L);
+        *reinterpret_cast<float4*>(out + (((int64_t)b * L + i) * H + h) * HD + d) = o;
     }
 }
 
@@ -354,48 +399,39 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ gqkv, int L, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* q = smem;
-    float* k = q + LMAX * HD;
-    float* v = k + LMAX * HP;
-    float* go = v + LMAX * HP;          // [L][64]
-    float* p = go + LMAX * HD;          // [L][L+1]
-    float* ds = p + LMAX * (LMAX + 1);  // [L][L+1]
+    float* k = q + LMAX * HS;
+    float* v = k + LMAX * HS;
+    float* go = v + LMAX * HS;
+    float* p = go + LMAX * HS;
+    float* ds = p + LMAX * HS;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int LP = L + 1;
+    lds_zero(smem, 6 * LMAX * HS / 4);
+    __syncthreads();
     load_qkv(qkv, b, h, L, H, q, k, v);
-    for (int e = threadIdx.x; e < L * HD; e += 256) {
-        const int t = e >> 6, d = e & 63;
-        go[t * HD + d] = gout[(((int64_t)b * L + t) * H + h) * HD + d];
+    for (int e = threadIdx.x; e < L * 16; e += 256) {
+        const int t = e >> 4, d = (e & 15) * 4;
+        *reinterpret_cast<float4*>(go + t * HS + d) = *reinterpret_cast<const float4*>(gout + (((int64_t)b * L + t) * H + h) * HD + d);
     }
     __syncthreads();
     softmax_probs(q, k, p, L);
-    // dP[i][j] = go_i . v_j
-    for (int e = threadIdx.x; e < L * L; e += 256) {
-        const int i = e / L, jj = e - i * L;
-        float s = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < HD; ++d) s += go[i * HD + d] * v[jj * HP + d];
-        ds[i * LP + jj] = s;
-    }
+    rows_dot_rows(go, v, ds, L, 1.f);  // dP[i][j] = go_i . v_j
     __syncthreads();
     if (threadIdx.x < L) {  // dS = P * (dP - sum_j dP*P)
         const int i = threadIdx.x;
         float dot = 0.f;
-        for (int jj = 0; jj < L; ++jj) dot += ds[i * LP + jj] * p[i * LP + jj];
-        for (int jj = 0; jj < L; ++jj) ds[i * LP + jj] = p[i * LP + jj] * (ds[i * LP + jj] - dot);
+        for (int jj = 0; jj < L; ++jj) dot += ds[i * HS + jj] * p[i * HS + jj];
+        for (int jj = 0; jj < L; ++jj) ds[i * HS + jj] = p[i * HS + jj] * (ds[i * HS + jj] - dot);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < L * HD; e += 256) {
-        const int t = e >> 6, d = e & 63;
-        float gq = 0.f, gk = 0.f, gv = 0.f;
-        for (int u = 0; u < L; ++u) {
-            gq += ds[t * LP + u] * k[u * HP + d];   // dQ_t = sum_j dS[t][j] K_j
-            gk += ds[u * LP + t] * q[u * HD + d];   // dK_t = sum_i dS[i][t] Q_i
-            gv += p[u * LP + t] * go[u * HD + d];   // dV_t = sum_i P[i][t] dO_i
-        }
+    for (int e = threadIdx.x; e < L * 16; e += 256) {
+        const int t = e >> 4, d = (e & 15) * 4;
+        const float4 gq = weighted_rows<false>(ds, k, t, d, L);  // dQ_t = sum_j dS[t][j] K_j
+        const float4 gk = weighted_rows<true>(ds, q, t, d, L);   // dK_t = sum_i dS[i][t] Q_i
+        const float4 gv = weighted_rows<true>(p, go, t, d, L);   // dV_t = sum_i P[i][t] dO_i
         float* dst = gqkv + (((int64_t)b * L + t) * 3 * H + h) * HD + d;
-        dst[0] = gq * 0.125f;
-        dst[(int64_t)H * HD] = gk * 0.125f;
-        dst[(int64_t)2 * H * HD] = gv;
+        *reinterpret_cast<float4*>(dst) = make_float4(gq.x * 0.125f, gq.y * 0.125f, gq.z * 0.125f, gq.w * 0.125f);
+        *reinterpret_cast<float4*>(dst + (int64_t)H * HD) = make_float4(gk.x * 0.125f, gk.y * 0.125f, gk.z * 0.125f, gk.w * 0.125f);
+        *reinterpret_cast<float4*>(dst + (int64_t)2 * H * HD) = gv;
     }
 }
 
@@ -484,7 +520,7 @@ extern "C" int w2e_attn_fwd(const float* qkv, float* out, int batch, int seq, in
     W2E_REQUIRE(qkv && out, "attn_fwd: null tensor");
     W2E_REQUIRE(seq > 0 && seq <= LMAX && heads > 0 && batch >= 0, "attn_fwd: seq %d (max %d), heads %d", seq, LMAX, heads);
     if (batch == 0) return 0;
-    const size_t lds = sizeof(float) * (LMAX * HD + 2 * LMAX * HP + LMAX * (LMAX + 1));
+    const size_t lds = sizeof(float) * 4 * LMAX * HS;
     static int configured_fwd = -1;
     if (configured_fwd != 0) configured_fwd = set_big_lds((const void*)attn_fwd_kernel, lds);
     W2E_REQUIRE(configured_fwd == 0, "attn_fwd: cannot raise the dynamic LDS limit to %zu B", lds);
@@ -497,7 +533,7 @@ extern "C" int w2e_attn_bwd(const float* qkv, const float* gout, float* gqkv, in
     W2E_REQUIRE(qkv && gout && gqkv, "attn_bwd: null tensor");
     W2E_REQUIRE(seq > 0 && seq <= LMAX && heads > 0 && batch >= 0, "attn_bwd: seq %d (max %d), heads %d", seq, LMAX, heads);
     if (batch == 0) return 0;
-    const size_t lds = sizeof(float) * (2 * LMAX * HD + 2 * LMAX * HP + 2 * LMAX * (LMAX + 1));
+    const size_t lds = sizeof(float) * 6 * LMAX * HS;
     static int configured = -1;
     if (configured != 0) configured = set_big_lds((const void*)attn_bwd_kernel, lds);
     W2E_REQUIRE(configured == 0, "attn_bwd: cannot raise the dynamic LDS limit to %zu B", lds);
