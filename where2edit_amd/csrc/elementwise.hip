@@ -315,15 +315,21 @@ __global__ __launch_bounds__(256) void demod_fwd_kernel(const float* __restrict_
 //   dz[b,o] = sum_p gpre * (d*z)  (= s1 - nw*s2 - bias*s3 from the fused-activation reductions, or given)
 //   gd = dz / d;  dd/ds[b,i] = -d^3 * wsq[o,i] * s[b,i]   =>   gs[b,i] += -s[b,i] * sum_o dz[b,o]*d[b,o]^2*wsq[o,i]
 // Block = (b, 256 input channels): coefficients in LDS, threads over i (coalesced wsq rows).
+constexpr int DEMOD_OCH = 32;
 __global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ dz_in,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ d, const float* __restrict__ s,
                                                         const float* __restrict__ wsq, float* __restrict__ gs,
                                                         float* __restrict__ gd_out, int Cin, int Cout) {
-    extern __shared__ float coef[];  // [Cout]
+    // blockIdx.z slices the output channels (DEMOD_OCH per block: the sum over o is a chain of dependent-latency loads,
+    // so it is cut short and spread over the chip); the slices add their part onto gs atomically.
+    __shared__ float coef[DEMOD_OCH];
     const int b = blockIdx.y;
+    const int o_lo = blockIdx.z * DEMOD_OCH;
+    const int o_n = (Cout - o_lo < DEMOD_OCH) ? Cout - o_lo : DEMOD_OCH;
     const float nw = noise_w ? noise_w[0] : 0.f;
-    for (int o = threadIdx.x; o < Cout; o += 256) {
+    for (int oo = threadIdx.x; oo < o_n; oo += 256) {
+        const int o = o_lo + oo;
         float dz;
         if (sums) {
             const float* q = sums + ((int64_t)b * Cout + o) * 3;
@@ -332,16 +338,17 @@ __global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict_
             dz = dz_in[(int64_t)b * Cout + o];
         }
         const float dv = d[(int64_t)b * Cout + o];
-        coef[o] = dz * dv * dv;
+        coef[oo] = dz * dv * dv;
         if (gd_out && blockIdx.x == 0) gd_out[(int64_t)b * Cout + o] = dz / dv;
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cin) return;
     float acc = 0.f;
-#pragma unroll 8
-    for (int o = 0; o < Cout; ++o) acc += coef[o] * wsq[(int64_t)o * Cin + i];
-    gs[(int64_t)b * Cin + i] -= s[(int64_t)b * Cin + i] * acc;
+    const float* wq = wsq + (int64_t)o_lo * Cin + i;
+#pragma unroll 16
+    for (int oo = 0; oo < o_n; ++oo) acc += coef[oo] * wq[(int64_t)oo * Cin];
+    atomicAdd(&gs[(int64_t)b * Cin + i], -s[(int64_t)b * Cin + i] * acc);
 }
 
 
@@ -526,8 +533,8 @@ int w2e_demod_bwd(const float* sums, const float* dz, const float* noise_w, cons
     W2E_REQUIRE(d && s && wsq && gs, "demod_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && cin > 0 && cout > 0 && batch < 65536, "demod_bwd: bad dims");
     if (batch == 0) return 0;
-    dim3 grid((unsigned)ceil_div(cin, 256), (unsigned)batch);
-    demod_bwd_kernel<<<grid, 256, sizeof(float) * cout, (hipStream_t)stream>>>(sums, dz, noise_w, bias, d, s, wsq, gs, gd, cin, cout);
+    dim3 grid((unsigned)ceil_div(cin, 256), (unsigned)batch, (unsigned)ceil_div(cout, DEMOD_OCH));
+    demod_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sums, dz, noise_w, bias, d, s, wsq, gs, gd, cin, cout);
     W2E_LAUNCH_CHECK("demod_bwd");
     return 0;
 }
