@@ -13,4 +13,7 @@ timeout -k 10 200 python3 tools/layer_bench.py > $O/layer_bench.txt 2>&1
 echo layer done
 timeout -k 10 200 python3 tools/mem_bench.py > $O/mem_bench.txt 2>&1
 echo mem done
-find $O -name '*.csv' | head -20
+
+timeout -k 10 400 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
+echo bench done
+timeout -k 10 60 tools/bin/mfma_peak > $O/mfma_peak.txt 2>&1 || true
