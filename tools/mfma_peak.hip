@@ -19,8 +19,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(float* out, const float* in, int
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-// Same loop, but every MFMA reads a different pair of operand registers holding random data (what a real GEMM does):
-// operand toggling costs power, and the sustained clock -- hence the rate -- drops below the constant-operand figure.
+// Same loop, but every MFMA reads a different pair of operand registers holding random data (what a real GEMM does).
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void kv(float* out, const float* in, int iters) {
     f32x16 acc[4];
@@ -32,7 +31,7 @@ __global__ __launch_bounds__(64 * WAVES) void kv(float* out, const float* in, in
         for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + i) & 7], acc[i], 0, 0, 0);
-        a[it & 7] = -a[it & 7];
+        a[0] = -a[0];  // (static index: a dynamically indexed register array costs the loop 7 %)
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
