@@ -152,6 +152,18 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
     float kr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) kr[i] = p.flip ? p.kern[15 - i] : p.kern[i];
+    // rank-1 test (uniform): k[ky][kx] == kv[ky] * kh[kx] with kh = row 0, kv = column 0 / k[0][0]
+    float kh[4], kv[4];
+    bool separable = kr[0] != 0.f;
+    {
+        float kmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kmax = fmaxf(kmax, fabsf(kr[i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kh[i] = kr[i], kv[i] = separable ? kr[4 * i] / kr[0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) separable = separable && fabsf(kr[i] - kv[i >> 2] * kh[i & 3]) <= 1e-7f * kmax;
+    }
     const float nw = (ACT && p.noise) ? p.noise_w[0] : 0.f;
     const int hp = (p.in_h + 1) >> 1, wpp = (((p.in_w + 1) >> 1) + 3) & ~3;
     const int64_t plane_stride = PLANAR ? (int64_t)4 * hp * wpp : (int64_t)p.in_h * p.in_w;
@@ -246,16 +258,30 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
         const int plane = item / tiles_y, ty = item - plane * tiles_y;
         const int oy0 = ty * TH + yb;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (separable) {  // k = kv (x) kh (every StyleGAN2 blur is an outer product): 44 + 32 FMAs instead of 128
 #pragma unroll
-        for (int r = 0; r < 11; ++r) {  // staged row yb+r feeds output row j with ky = r - j
-            if ((p.tune & 2) && r > 0) break;
-            const float* rowp = smem + (yb + r) * PE;
-            const float w0 = rowp[woff[0]], w1 = rowp[woff[1]], w2 = rowp[woff[2]], w3 = rowp[woff[3]];
+            for (int r = 0; r < 11; ++r) {  // staged row yb+r: horizontal pass once, then it feeds output row j with ky = r - j
+                if ((p.tune & 2) && r > 0) break;
+                const float* rowp = smem + (yb + r) * PE;
+                const float hr = kh[0] * rowp[woff[0]] + kh[1] * rowp[woff[1]] + kh[2] * rowp[woff[2]] + kh[3] * rowp[woff[3]];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ky = r - j;
-                if (ky >= 0 && ky < 4)
-                    acc[j] += kr[ky * 4 + 0] * w0 + kr[ky * 4 + 1] * w1 + kr[ky * 4 + 2] * w2 + kr[ky * 4 + 3] * w3;
+                for (int j = 0; j < 8; ++j) {
+                    const int ky = r - j;
+                    if (ky >= 0 && ky < 4) acc[j] += kv[ky] * hr;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 11; ++r) {  // staged row yb+r feeds output row j with ky = r - j
+                if ((p.tune & 2) && r > 0) break;
+                const float* rowp = smem + (yb + r) * PE;
+                const float w0 = rowp[woff[0]], w1 = rowp[woff[1]], w2 = rowp[woff[2]], w3 = rowp[woff[3]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ky = r - j;
+                    if (ky >= 0 && ky < 4)
+                        acc[j] += kr[ky * 4 + 0] * w0 + kr[ky * 4 + 1] * w1 + kr[ky * 4 + 2] * w2 + kr[ky * 4 + 3] * w3;
+                }
             }
         }
         float e_scale = 1.f, e_bias = 0.f;
