@@ -30,7 +30,11 @@ G_FWD_GFLOP_1024 = 148.13  # 3x3 modconv stack per image forward (To
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def make_opts(size, batch):
+def make_opts(size, batch, workload=2):
+    if workload == 3:  # BASELINE configs[2]: region-attention mask at layer 13 + id_loss
+        o = make_opts(size, batch)
+        o.id_lambda, o.attention_layer = 0.1, 13
+        return o
     return types.SimpleNamespace(
         mapper_type="LevelsMapper", no_coarse_mapper=False, no_medium_mapper=False, no_fine_mapper=False,
         work_in_stylespace=False, stylegan_size=size, checkpoint_path=None, stylegan_weights=None,
@@ -38,14 +42,19 @@ def make_opts(size, batch):
         latent_l2_lambda=0.8, max_steps=0, description="synthetic prompt")
 
 
-def build_coach(size, batch, device, data_parallel, clip_backend):
+def build_coach(size, batch, device, data_parallel, clip_backend, workload=2):
     from where2edit_amd.clip_loss import CLIPLoss
     from where2edit_amd.clip_vit import CLIP
     from where2edit_amd.coach import Coach, synthetic_tokens
     from where2edit_amd.styleclip_mapper import StyleCLIPMapper
     torch.manual_seed(0)  # identical replicas on every rank
-    opts = make_opts(size, batch)
+    opts = make_opts(size, batch, workload)
     net = StyleCLIPMapper(opts)
+    if workload == 3:  # same parameters, the generator class that can blend (attention/attention_model.py)
+        from where2edit_amd.attention_model import Generator as AttentionGenerator
+        dec = AttentionGenerator(size, 512, 8)
+        dec.load_state_dict(net.decoder.state_dict(), strict=True)
+        net.decoder = dec
     with torch.no_grad():  # the reference inits these to 0; give them values so the fused epilogue paths are live
         for name, p in net.decoder.named_parameters():
             if name.endswith("noise.weight") or name.endswith("activate.bias") or name.endswith("to_rgb1.bias") \
@@ -126,6 +135,9 @@ def main():
     ap.add_argument("--clip-backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--workload", type=int, default=2, choices=[2, 3],
+                    help="BASELINE configs index + 1: 2 = clip_loss mapper step (the headline, default); 3 = the same step with "
+                         "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8)")
     args = ap.parse_args()
 
     from where2edit_amd import dist as wd
@@ -135,8 +147,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = f"cuda:{local}"
     torch.cuda.set_device(device)
-    coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend)
+    coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend, args.workload)
     w = synthetic_latents(coach.net.decoder, args.batch, rank)
+    mask = None
+    if args.workload == 3:  # seeded U(0,1) mask at the resolution of layer 13
+        res = 4 * 2 ** ((13 - 1) // 3) if args.size == 1024 else max(4, args.size // 16)
+        mask = torch.rand(args.batch, 1, res, res, generator=torch.Generator().manual_seed(77 + rank)).to(device)
 
     def barrier():
         if world > 1:
@@ -144,14 +160,14 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        coach.train_step(w)
+        coach.train_step(w, mask)
     barrier()
     timer = None if args.no_kernel_timing else profiling.KernelTimer()
     if timer is not None:
         timer.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last = coach.train_step(w)
+        last = coach.train_step(w, mask)
     barrier()
     dt = time.perf_counter() - t0
     if timer is not None:
@@ -174,8 +190,11 @@ def main():
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
-                               f"LevelsMapper, Ranger, id_lambda=0", "global_batch": global_batch,
+        "config": {"workload": (f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
+                                f"LevelsMapper, Ranger, id_lambda=0") if args.workload == 2 else
+                               (f"FFHQ-{args.size} mapper step with the region-attention mask blend at layer 13 (attention_model.py) "
+                                f"+ clip_loss + id_loss (IR-SE50, stock ops), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
+                   "global_batch": global_batch,
                    "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "final_loss": loss},
     }
     if timer is not None:

@@ -141,3 +141,39 @@ def test_id_loss_term_on_gpu_matches_cpu_execution():
         got, zero = loss_mod.to(DEV)(x_hat, x)
     assert zero == 0
     assert abs(float(got) - float(ref)) <= 1e-3 * max(1.0, abs(float(ref)))
+
+
+def test_region_attention_step_matches_oracle():
+    """BASELINE configs[2] shape of the step: the edited pass blends layer 13 (and the ToRGB after it) with the
+    unedited pass's activations under a mask (attention_model.py:473-676) -- forward pieces and the mapper
+    gradient of clip + latent-L2 through the blend against the oracle."""
+    from oracle import clip_model as OC
+    from oracle import mappers as OM
+    from where2edit_amd.attention_model import Generator as AttentionGenerator
+    coach, msd, tokens = _coach(_opts(attention_layer=13))
+    dec = AttentionGenerator(SIZE, 512, 8)
+    dec.load_state_dict(seeded.generator_state_dict(SIZE), strict=True)
+    coach.net.decoder = dec.to(DEV).requires_grad_(False)
+    w = seeded.wplus_latents(2, OG.n_latent(SIZE), salt=23)
+    mask = (seeded.tensor("region.mask", (2, 1, 16, 16)) * 0.5 + 0.5).clamp(0, 1)
+    # oracle
+    gsd, csd = seeded.generator_state_dict(SIZE), seeded.clip_state_dict(**CLIP_TINY)
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    with torch.no_grad():
+        x_o, _, _, feats_o = OG.generator_forward(gsd, [w], size=SIZE, input_is_latent=True, randomize_noise=False,
+                                                  return_features=True)
+    wh_o = w + 0.1 * OM.levels_mapper(osd, w)
+    xh_o, wh_o, _ = OG.generator_forward(gsd, [wh_o], size=SIZE, input_is_latent=True, randomize_noise=False,
+                                         return_latents=True, attention_layer=13, attention_map=mask, feature_map=feats_o)
+    loss_o = OC.clip_loss(csd, xh_o, tokens, SIZE).mean() + 0.8 * torch.nn.functional.mse_loss(wh_o, w)
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    # HIP
+    x, x_hat, w_hat = coach.forward_pair(w.to(DEV), mask.to(DEV))
+    assert_close(x, x_o, 1e-4, "x = G(w)"), assert_close(x_hat, xh_o, 1e-4, "blended x_hat"), assert_close(w_hat, wh_o, 1e-5, "w_hat")
+    d = coach.train_step(w.to(DEV), mask.to(DEV))
+    assert abs(float(d["loss"]) - loss_o.item()) <= 1e-4 * abs(loss_o.item())
+    params = dict(coach.net.mapper.named_parameters())
+    flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
+    flat_o = torch.cat([g.reshape(-1) for g in grads_o])
+    assert_grad_close(flat_h, flat_o, "mapper gradients through the blend")

@@ -61,10 +61,24 @@ class Coach:
             return torch.optim.Adam(params, lr=self.opts.learning_rate)
         return Ranger(params, lr=self.opts.learning_rate)
 
-    def forward_pair(self, w):
-        """coach.py:80-89 (W+ and S-space branches)."""
+    def forward_pair(self, w, mask=None):
+        """coach.py:80-89 (W+ and S-space branches).  With `mask` [B,1,s,s] and opts.attention_layer > 0 (BASELINE
+        configs[2]) the edited image is generated the region-attention way (attention/run_attention.py:1104-1126): the
+        decoder is attention_model.Generator, the unedited pass also returns its 26 activations, and the edited pass
+        blends layer `attention_layer` (and the ToRGB after it) with them under the mask."""
         dec = self.net.decoder
         s_space = getattr(self.opts, "work_in_stylespace", False)
+        att_layer = getattr(self.opts, "attention_layer", 0)
+        if mask is not None and att_layer > 0:
+            if s_space:
+                raise NotImplementedError("region-attention blend with S-space mappers")
+            with torch.no_grad():
+                x, _, _, feats = dec([w], input_is_latent=True, randomize_noise=False, truncation=1, return_features=True)
+            self._x_ready = None
+            w_hat = w + 0.1 * self.net.mapper(w)
+            x_hat, w_hat, _ = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False, truncation=1,
+                                  attention_layer=att_layer, attention_map=mask, feature_map=feats)
+            return x, x_hat, w_hat
         main = torch.cuda.current_stream()
         if self._side is not None:
             self._side.wait_stream(main)
@@ -112,13 +126,13 @@ class Coach:
         loss_dict["loss"] = loss.detach()
         return loss, loss_dict
 
-    def train_step(self, w):
+    def train_step(self, w, mask=None):
         """One mapper step on this rank's shard of latents (the unit of the headline metric)."""
         if self.bucket is not None:
             self.bucket.zero()
         else:
             self.optimizer.zero_grad()
-        x, x_hat, w_hat = self.forward_pair(w)
+        x, x_hat, w_hat = self.forward_pair(w, mask)
         loss, loss_dict = self.calc_loss(w, x, w_hat, x_hat)
         loss.backward()
         if self.bucket is not None:
