@@ -63,7 +63,14 @@ def load():
     return _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a void*.  (torch.cuda.current_stream() builds a Python Stream
+    object per call, ~10 us -- 2 ms of host time per mapper step; the raw accessor is ~0.3 us.)"""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
