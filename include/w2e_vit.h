@@ -32,6 +32,9 @@ int w2e_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 /* Input gradient only (gamma/beta are frozen). */
 int w2e_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd,
                       float* gx, int64_t rows, int dim, void* stream);
+/* The same plus `add` [rows, dim] (or NULL): gx = LN'(gy) + add -- the residual branch of a pre-LN block joins here. */
+int w2e_layernorm_bwd_add(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* add, float* gx, int64_t rows, int dim, void* stream);
 
 /* Multi-head self-attention core on a packed QKV tensor [B, L, 3, heads, 64] (the layout nn.MultiheadAttention's
  * in_proj produces): out[B, L, heads*64] = softmax(Q K^T / 8) V per (batch, head).  L <= 64, head dim = 64.

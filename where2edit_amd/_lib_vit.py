@@ -7,6 +7,7 @@ PROTOS = {
     "w2e_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "w2e_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "w2e_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "w2e_layernorm_bwd_add": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "w2e_attn_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "w2e_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
 }

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // gx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ gx,
-                                                            int64_t rows, int dim) {
+                                                            const float* __restrict__ rstd, const float* __restrict__ add,
+                                                            float* __restrict__ gx, int64_t rows, int dim) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < LN_MAX_PER_LANE; ++t) {
         const int c = lane + 64 * t;
-        if (c < dim) gx[row * dim + c] = rs * (gg[t] - s1 - xh[t] * s2);
+        if (c < dim) gx[row * dim + c] = rs * (gg[t] - s1 - xh[t] * s2) + (add ? add[row * dim + c] : 0.f);
     }
 }
 
@@ -506,14 +506,19 @@ extern "C" int w2e_layernorm_fwd(const float* x, const float* gamma, const float
     return 0;
 }
 
-extern "C" int w2e_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                 float* gx, int64_t rows, int dim, void* stream) {
+extern "C" int w2e_layernorm_bwd_add(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     const float* add, float* gx, int64_t rows, int dim, void* stream) {
     W2E_REQUIRE(gy && x && gamma && mean && rstd && gx, "layernorm_bwd: null tensor");
     W2E_REQUIRE(dim > 0 && dim <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: dim %d unsupported", dim);
     if (rows <= 0) return 0;
-    layernorm_bwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(gy, x, gamma, mean, rstd, gx, rows, dim);
+    layernorm_bwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(gy, x, gamma, mean, rstd, add, gx, rows, dim);
     W2E_LAUNCH_CHECK("layernorm_bwd");
     return 0;
+}
+
+extern "C" int w2e_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                 float* gx, int64_t rows, int dim, void* stream) {
+    return w2e_layernorm_bwd_add(gy, x, gamma, mean, rstd, nullptr, gx, rows, dim, stream);
 }
 
 extern "C" int w2e_attn_fwd(const float* qkv, float* out, int batch, int seq, int heads, void* stream) {

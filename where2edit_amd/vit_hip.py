@@ -140,12 +140,66 @@ def layer_norm(x, ln):
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
 
 
+def _ln_fwd(x2, w, b, eps):
+    rows, dim = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, device=x2.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x2.device, dtype=torch.float32)
+    call("w2e_layernorm_fwd", ptr(x2), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, dim, float(eps), stream_ptr())
+    return y, mean, rstd
+
+
+class _ResBlock(torch.autograd.Function):
+    """One whole ResidualAttentionBlock as ONE autograd node (9 launches forward, 9 backward): the per-op Functions
+    above cost ~25 us of host time per kernel in autograd bookkeeping, which starves the GPU on these 5-20 us kernels;
+    the residual joins of the backward ride in the LayerNorm-backward kernel instead of two extra `add` launches."""
+
+    @staticmethod
+    def forward(ctx, x, heads, eps1, eps2, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b):
+        _frozen(ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b)
+        b, l, dim = x.shape
+        if dim != heads * 64:
+            raise RuntimeError(f"attention kernel needs head_dim 64 (got width {dim} with {heads} heads)")
+        x2 = _c(x).reshape(b * l, dim)
+        y1, mean1, rstd1 = _ln_fwd(x2, ln1_w, ln1_b, eps1)
+        qkv = _gemm(y1, in_w, True, bias=in_b)
+        att = torch.empty((b * l, dim), device=x.device, dtype=torch.float32)
+        call("w2e_attn_fwd", ptr(qkv), ptr(att), b, l, heads, stream_ptr())
+        x_mid = _gemm(att, out_w, True, bias=out_b, residual=x2)
+        y2, mean2, rstd2 = _ln_fwd(x_mid, ln2_w, ln2_b, eps2)
+        h = _gemm(y2, fc_w, True, bias=fc_b)
+        out = _gemm(h, proj_w, True, bias=proj_b, residual=x_mid, a_gelu=True)
+        ctx.save_for_backward(x2, mean1, rstd1, qkv, x_mid, mean2, rstd2, h, ln1_w, in_w, out_w, ln2_w, fc_w, proj_w)
+        ctx.geom = (b, l, dim, heads)
+        return out.reshape(b, l, dim)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x2, mean1, rstd1, qkv, x_mid, mean2, rstd2, h, ln1_w, in_w, out_w, ln2_w, fc_w, proj_w = ctx.saved_tensors
+        b, l, dim, heads = ctx.geom
+        rows = b * l
+        g = _c(gout).reshape(rows, dim)
+        gh = _gemm(g, proj_w, False, gelu_grad_aux=h)           # through c_proj and QuickGELU'
+        gy2 = _gemm(gh, fc_w, False)                            # through c_fc
+        g_mid = torch.empty_like(x_mid)                         # through ln_2, + the residual branch
+        call("w2e_layernorm_bwd_add", ptr(gy2), ptr(x_mid), ptr(ln2_w), ptr(mean2), ptr(rstd2), ptr(g), ptr(g_mid), rows, dim,
+             stream_ptr())
+        ga = _gemm(g_mid, out_w, False)                         # through out_proj
+        gqkv = torch.empty_like(qkv)
+        call("w2e_attn_bwd", ptr(qkv), ptr(ga), ptr(gqkv), b, l, heads, stream_ptr())
+        gy1 = _gemm(gqkv, in_w, False)                          # through in_proj
+        gx = torch.empty_like(x2)                               # through ln_1, + the residual branch
+        call("w2e_layernorm_bwd_add", ptr(gy1), ptr(x2), ptr(ln1_w), ptr(mean1), ptr(rstd1), ptr(g_mid), ptr(gx), rows, dim,
+             stream_ptr())
+        return (gx.reshape(b, l, dim),) + (None,) * 15
+
+
 def resblock_forward(blk, x, heads):
     """ResidualAttentionBlock: x += out_proj(attn(in_proj(ln_1 x))); x += c_proj(QuickGELU(c_fc(ln_2 x)))."""
-    qkv = linear(layer_norm(x, blk.ln_1), blk.attn.in_proj_weight, blk.attn.in_proj_bias)
-    x = linear(_Attention.apply(qkv, heads), blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x)
-    h = linear(layer_norm(x, blk.ln_2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
-    return _GeluLinear.apply(h, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, x)
+    return _ResBlock.apply(x, heads, blk.ln_1.eps, blk.ln_2.eps, blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_weight,
+                           blk.attn.in_proj_bias, blk.attn.out_proj.weight, blk.attn.out_proj.bias, blk.ln_2.weight,
+                           blk.ln_2.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
 
 
 def vision_forward(vit, image):
