@@ -177,3 +177,60 @@ def test_region_attention_step_matches_oracle():
     flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
     flat_o = torch.cat([g.reshape(-1) for g in grads_o])
     assert_grad_close(flat_h, flat_o, "mapper gradients through the blend")
+
+
+def test_stylespace_step_matches_oracle():
+    """coach.py:84-89 with work_in_stylespace: the latent is the list of 26 S-space codes, the mapper is
+    WithoutToRGBStyleSpaceMapper (17 sub-mappers), the decoder runs with input_is_stylespace.  FFHQ-1024 shapes
+    (STYLESPACE_DIMENSIONS is the 1024 generator's), batch 1: images, loss and mapper gradients against the oracle."""
+    from oracle import clip_model as OC
+    from oracle import mappers as OM
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.coach import Coach
+    from where2edit_amd.styleclip_mapper import StyleCLIPMapper
+    size = 1024
+    dims = OM.STYLESPACE_DIMENSIONS
+    idx = [c for c in range(len(dims)) if c not in range(1, len(dims), 3)]
+    opts = _opts(work_in_stylespace=True, stylegan_size=size, batch_size=1)
+    net = StyleCLIPMapper(opts)
+    gsd = seeded.generator_state_dict(size)
+    net.decoder.load_state_dict(gsd, strict=True)
+    msd = seeded.mapper_state_dict([f"mapper_{c}." for c in idx], [dims[c] for c in idx])
+    net.mapper.load_state_dict(msd, strict=True)
+    c = CLIP_TINY
+    clip = CLIP(embed_dim=c["embed_dim"], vision_layers=c["vision_layers"], vision_width=c["vision_width"],
+                context_length=c["context_length"], vocab_size=c["vocab_size"], transformer_width=c["text_width"],
+                transformer_heads=1, transformer_layers=c["text_layers"])
+    csd = seeded.clip_state_dict(**c)
+    clip.load_state_dict(csd, strict=True)
+    tokens = torch.from_numpy(golden("clip_hf")["tiny.tokens"])[:1]
+    coach = Coach(opts, net=net, clip_loss=CLIPLoss(opts, model=clip), text_inputs=tokens, device=DEV)
+    # S-space codes of a W+ latent (what the reference's S-space datasets hold)
+    w_plus = seeded.wplus_latents(1, OG.n_latent(size), salt=29)
+    with torch.no_grad():
+        _, _, codes = OG.generator_forward(gsd, [w_plus], size=size, input_is_latent=True, randomize_noise=False,
+                                           return_latents=True)
+    codes = [s.detach() for s in codes]
+    # oracle step
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    with torch.no_grad():
+        x_o, _ = OG.generator_forward(gsd, [codes], size=size, input_is_stylespace=True, randomize_noise=False)
+    delta = OM.without_torgb_stylespace_mapper(osd, codes)
+    wh_o = [s + 0.1 * d for s, d in zip(codes, delta)]
+    xh_o, _, _ = OG.generator_forward(gsd, [wh_o], size=size, input_is_stylespace=True, randomize_noise=False,
+                                      return_latents=True)
+    l2_o = sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(wh_o, codes))
+    loss_o = OC.clip_loss(csd, xh_o, tokens, size).mean() + 0.8 * l2_o
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    # HIP
+    codes_d = [s.to(DEV) for s in codes]
+    x, x_hat, w_hat = coach.forward_pair(codes_d)
+    assert_close(x, x_o, 1e-4, "x = G(s)"), assert_close(x_hat, xh_o, 1e-4, "x_hat")
+    d = coach.train_step(codes_d)
+    assert abs(float(d["loss"]) - loss_o.item()) <= 1e-4 * abs(loss_o.item())
+    params = dict(coach.net.mapper.named_parameters())
+    flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
+    flat_o = torch.cat([g.reshape(-1) for g in grads_o])
+    assert_grad_close(flat_h, flat_o, "S-space mapper gradients")
