@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""The ViT-B/32 GEMM shapes of one step at batch 4 (M = 200): time per call of w2e_gemm vs torch (hipBLASLt)."""
+"""The ViT-B/32 GEMM shapes of one step at batch 4 (M = 200): wall time per call of w2e_gemm vs torch (hipBLASLt).
+Back-to-back calls of 10-25 us kernels are partly host-bound (ctypes + allocation ~15 us per call): for kernel durations
+use rocprofv3 --kernel-trace on tools/vit_bench.py; this tool is for relative comparisons and split-K sweeps
+(W2E_TUNE_GEMM_S=<splits>)."""
 import os
 import sys
 
