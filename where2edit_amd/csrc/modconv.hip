@@ -331,33 +331,58 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         float xr[MAXX][KCP];
         float sc[KCP];
 
+        // The staging instructions of a chunk issue while the matrix pipe is idle (every wave of the workgroup is in the
+        // same phase), so they are kept to the loads themselves -- buffer loads: `descriptor (SGPRs) + per-thread byte
+        // offset (one VGPR, computed once per tile) + per-channel scalar offset`, no branches, no address arithmetic.
+        // The hardware range check returns 0 for offsets past the descriptor's size, which IS the zero padding: halo
+        // pixels outside the image and unused prefetch slots carry an out-of-range offset.  (The descriptor spans the K
+        // channel planes of one image -- on gfx9 the scalar offset takes part in the range check; channels past K are
+        // clamped to the last one, their sc is 0.)
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (int64_t)b * p.K * in_plane), (short)0, (int)(unsigned)((int64_t)p.K * in_plane * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.wp), (short)0, (int)(((p.K + 7) >> 3) * 9 * 2 * p.N * 16), 0x00020000);
+        unsigned xoff[MAXX], woff[WQ];
+#pragma unroll
+        for (int t = 0; t < MAXX; ++t) {
+            const int idx = tid + t * NT;
+            const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
+            const int px = idx - py * p.pw;
+            const int iy = oy0 + py, ix = ox0 + px;
+            const bool inb = idx < patch && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            xoff[t] = inb ? (unsigned)(iy * p.in_w + ix) * 4u : 0xfffffff0u;
+        }
+        const unsigned wgroup_bytes = 9u * 2u * (unsigned)p.N * 16u;  // one 8-channel group of the packed weights
+#pragma unroll
+        for (int t = 0; t < WQ; ++t) {
+            const int q = tid + t * NT;
+            const int o = q % TN, rh = q / TN;             // rh = (sub*NTAPS + slot)*2 + h
+            const int hh = rh & 1, ss = rh >> 1;
+            const int slot = ss % T::N, sub = ss / T::N;
+            const int tap = T::ta(slot) * 3 + T::tb(slot);
+            // output channels past N read channel N-1 (their accumulator rows are never stored)
+            const int oc = n0 + o < p.N ? n0 + o : p.N - 1;
+            woff[t] = q < WQ4 ? (unsigned)sub * wgroup_bytes + (unsigned)(((tap * 2 + hh) * p.N + oc) * 16) : 0xfffffff0u;
+        }
+
         auto prefetch = [&](int k0) __attribute__((always_inline)) {
+            const unsigned wbase = (unsigned)(k0 >> 3) * wgroup_bytes;  // groups past K fall out of the descriptor: zeros
 #pragma unroll
             for (int t = 0; t < WQ; ++t) {
-                const int q = tid + t * NT;
-                const int o = q % TN, rh = q / TN;             // rh = (sub*NTAPS + slot)*2 + h
-                const int hh = rh & 1, ss = rh >> 1;
-                const int slot = ss % T::N, sub = ss / T::N;
-                const int tap = T::ta(slot) * 3 + T::tb(slot);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < WQ4 && k0 + sub * 8 < k_hi && n0 + o < p.N)
-                    v = *reinterpret_cast<const float4*>(p.wp + ((((int64_t)((k0 >> 3) + sub) * 9 + tap) * 2 + hh) * p.N + n0 + o) * 4);
-                wr[t] = v;
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[t] + wbase, 0, 0));
+                wr[t] = make_float4(v[0], v[1], v[2], v[3]);
             }
 #pragma unroll
             for (int ci = 0; ci < KCP; ++ci)
                 sc[ci] = (k0 + ci < k_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + k0 + ci] : 1.f) : 0.f;
-            const float* xb = p.x + ((int64_t)b * p.K + k0) * in_plane;
 #pragma unroll
-            for (int t = 0; t < MAXX; ++t) {
-                const int idx = tid + t * NT;
-                const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
-                const int px = idx - py * p.pw;
-                const int iy = oy0 + py, ix = ox0 + px;
-                const bool inb = idx < patch && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-                const float* src = xb + (int64_t)iy * p.in_w + ix;
+            for (int ci = 0; ci < KCP; ++ci) {
+                const int cc = k0 + ci < p.K ? k0 + ci : p.K - 1;        // uniform
+                const unsigned soff = (unsigned)cc * (unsigned)(in_plane * 4);
 #pragma unroll
-                for (int ci = 0; ci < KCP; ++ci) xr[t][ci] = (inb && k0 + ci < k_hi) ? src[ci * in_plane] : 0.f;
+                for (int t = 0; t < MAXX; ++t)
+                    xr[t][ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[t], soff, 0));
             }
         };
         auto commit = [&]() __attribute__((always_inline)) {
@@ -607,6 +632,10 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE((dot_with == nullptr) == (dot_out == nullptr), "modconv3x3: dot_with and dot_out go together");
     W2E_REQUIRE(!noise || noise_w, "modconv3x3: noise without noise_w");
     if (batch == 0) return 0;
+    {   // the kernel addresses one image's input with 32-bit byte offsets (buffer loads)
+        const int64_t ih = mode == W2E_CONV_DOWN ? 2 * (int64_t)h + 1 : h, iw = mode == W2E_CONV_DOWN ? 2 * (int64_t)w + 1 : w;
+        W2E_REQUIRE((int64_t)k_ch * ih * iw * 4 < ((int64_t)1 << 32), "modconv3x3: one image of the input exceeds 4 GB");
+    }
     hipStream_t s = (hipStream_t)stream;
 
     ConvParams p{};
