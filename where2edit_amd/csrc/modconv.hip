@@ -463,6 +463,19 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         nz[pb] = (EPI == EPI_ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
     }
     const int out_plane = is_up(MODE) ? 4 * (p.H + 1) * ((p.W + 4) & ~3) : p.out_h * p.out_w;
+    // Output (and dot_with) accesses as buffer operations on a descriptor spanning this image's N planes: per-lane byte
+    // offset (pixel, + 4 planes for the upper lane-half) computed once, per-register scalar offset = the output channel's
+    // plane.  Pixels outside the tile/image carry an out-of-range offset; channels >= N fall past the descriptor: the
+    // hardware drops those stores / returns 0 -- no branches, no 64-bit address arithmetic per access.
+    const unsigned plane_bytes = (unsigned)out_plane * 4u;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        p.y + (int64_t)b * p.N * out_plane, (short)0, (int)((unsigned)p.N * plane_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == EPI_DOT ? p.dot_with + (int64_t)b * p.N * out_plane : p.x), (short)0,
+        EPI == EPI_DOT ? (int)((unsigned)p.N * plane_bytes) : 0, 0x00020000);
+    unsigned yoff[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) yoff[pb] = valid[pb] ? (unsigned)pix[pb] * 4u + (unsigned)(4 * half) * plane_bytes : 0xfffffff0u;
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         float os[16], bs[16];
@@ -478,10 +491,10 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                 float dwv[8][NPB];
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
-                    const int o = n0 + (wo * NOB + ob) * 32 + ((r8 + rr) & 3) + 8 * ((r8 + rr) >> 2) + 4 * half;
-                    const float* dw = p.dot_with + (int64_t)(b * p.N + (o < p.N ? o : 0)) * out_plane;
+                    const unsigned soff = (unsigned)(n0 + (wo * NOB + ob) * 32 + ((r8 + rr) & 3) + 8 * ((r8 + rr) >> 2)) * plane_bytes;
 #pragma unroll
-                    for (int pb = 0; pb < NPB; ++pb) dwv[rr][pb] = dw[valid[pb] ? pix[pb] : 0];
+                    for (int pb = 0; pb < NPB; ++pb)
+                        dwv[rr][pb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, yoff[pb], soff, 0));
                 }
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
@@ -498,23 +511,30 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                 }
             }
         }
+        if (p.splits > 1) {  // split-K: fp32 atomics through plain pointers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // pass 2: stores only
-            const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (o >= p.N) continue;
-            float* yp = p.y + (int64_t)(b * p.N + o) * out_plane;
+            for (int r = 0; r < 16; ++r) {
+                const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.N) continue;
+                float* yp = p.y + (int64_t)(b * p.N + o) * out_plane;
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) {
-                if (!valid[pb]) continue;
-                float v = acc[ob][pb][r] * os[r];
-                if (EPI == EPI_ACT) {
-                    v += bs[r] + nz[pb];
-                    v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
+                for (int pb = 0; pb < NPB; ++pb)
+                    if (valid[pb]) atomicAdd(&yp[pix[pb]], acc[ob][pb][r] * os[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // pass 2: stores only
+                const unsigned soff = (unsigned)(n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2)) * plane_bytes;
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) {
+                    float v = acc[ob][pb][r] * os[r];
+                    if (EPI == EPI_ACT) {
+                        v += bs[r] + nz[pb];
+                        v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
+                    }
+                    if ((p.tune_skip & 1) && v != 123456.789f) continue;  // tuning aid: no stores, arithmetic kept alive
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[pb], soff, 0);
                 }
-                if (p.tune_skip & 1) {
-                    if (v == 123456.789f) yp[pix[pb]] = v;  // keeps the epilogue arithmetic alive
-                } else if (p.splits > 1) atomicAdd(&yp[pix[pb]], v);
-                else yp[pix[pb]] = v;
             }
         }
     }
@@ -635,6 +655,8 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     {   // the kernel addresses one image's input with 32-bit byte offsets (buffer loads)
         const int64_t ih = mode == W2E_CONV_DOWN ? 2 * (int64_t)h + 1 : h, iw = mode == W2E_CONV_DOWN ? 2 * (int64_t)w + 1 : w;
         W2E_REQUIRE((int64_t)k_ch * ih * iw * 4 < ((int64_t)1 << 32), "modconv3x3: one image of the input exceeds 4 GB");
+        const int64_t oplane = mode == W2E_CONV_UP ? 4 * ((int64_t)h + 1) * ((w + 4) & ~3) : (int64_t)h * w;
+        W2E_REQUIRE((int64_t)n_ch * oplane * 4 < ((int64_t)1 << 32) - 16 * oplane, "modconv3x3: one image of the output exceeds 4 GB");
     }
     hipStream_t s = (hipStream_t)stream;
 
