@@ -168,7 +168,6 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
     const int hp = (p.in_h + 1) >> 1, wpp = (((p.in_w + 1) >> 1) + 3) & ~3;
     const int64_t plane_stride = PLANAR ? (int64_t)4 * hp * wpp : (int64_t)p.in_h * p.in_w;
     const int row_len = PLANAR ? wpp : p.in_w;                       // floats per source row (a multiple of 4)
-    const int item_stride = PLANAR ? (TH / 2) * wpp : TH * p.in_w;   // source offset between vertically adjacent tiles
 
     const int tx = blockIdx.x % tiles_x, g0 = blockIdx.x / tiles_x, gstep = gridDim.x / tiles_x;
     const int ox0 = tx * TW, ix0 = ox0 - p.pad_x0;
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
     auto chunk0 = [&](int par) { return PLANAR ? (((ix0 - par + 1) >> 1) & ~3) : (ix0 & ~3); };
 
     // per-slot constants: slot -> (staged row r, parity, chunk q)
-    int s_r[NIT], s_src[NIT], s_lds[NIT];
+    int s_r[NIT], s_par[NIT], s_v4[NIT], s_lds[NIT];
     unsigned s_mask[NIT];  // bit k: element k of the chunk is image data (column inside [0, in_w))
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -200,24 +199,32 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
                 if (ix >= 0 && ix < p.in_w) m |= 1u << k;
             }
         }
-        const int ry = r - p.pad_y0;  // source row relative to the tile's first output row (TH is even: parity is fixed)
         s_r[it] = r;
         s_mask[it] = m;
-        s_src[it] = PLANAR ? ((((ry & 1) * 2 + par) * hp + (ry >> 1)) * wpp + v4) : (ry * p.in_w + v4);
+        s_par[it] = par;
+        s_v4[it] = v4;
         s_lds[it] = (par * PH + (r < PH ? r : 0)) * PE + 4 * q;
     }
 
+    // Loads and stores are buffer operations: a descriptor over the item's plane + a per-thread byte offset + the tile
+    // row's scalar offset; an invalid slot (row outside the image, chunk outside the row) carries an out-of-range offset
+    // and the hardware returns 0 -- no select on the loaded value (which would make the wave wait for the load at the
+    // issue site and undo the prefetch), no 64-bit address arithmetic per access.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned OOB = 0x80000000u;
     auto fetch = [&](int item, float4 (&reg)[NIT]) __attribute__((always_inline)) {
         const int plane = item / tiles_y, ty = item - plane * tiles_y;
-        const float* base = p.x + (int64_t)plane * plane_stride + (int64_t)ty * item_stride;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (int64_t)plane * plane_stride), (short)0, (int)(plane_stride * 4), 0x00020000);
         const int iy0 = ty * TH - p.pad_y0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int iy = iy0 + s_r[it];
             const bool ok = s_mask[it] != 0 && iy >= 0 && iy < p.in_h && !(p.tune & 1);
-            // branch-free: always load from a valid address (the slot's own, or the tile base), select afterwards
-            const float4 v = *reinterpret_cast<const float4*>(ok ? base + s_src[it] : p.x);
-            reg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            // element offset of the chunk inside the plane (all of it in the per-thread offset: never negative when ok)
+            const int off = PLANAR ? ((((iy & 1) * 2 + s_par[it]) * hp + (iy >> 1)) * wpp + s_v4[it]) : (iy * p.in_w + s_v4[it]);
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)off * 4u : OOB, 0, 0));
+            reg[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
     auto commit = [&](const float4 (&reg)[NIT]) __attribute__((always_inline)) {
@@ -289,11 +296,17 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
             if (p.out_scale) e_scale = p.out_scale[plane];
             if (p.bias) e_bias = p.bias[plane % p.channels];
         }
+        // rows past out_h fall past the descriptor (dropped / 0); columns past out_w carry OOB
+        const unsigned out_bytes = (unsigned)(p.out_h * p.out_w) * 4u;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)plane * p.out_h * p.out_w, (short)0,
+                                                                            (int)out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACT && p.noise ? p.noise : p.x), (short)0,
+                                                                            (ACT && p.noise) ? (int)out_bytes : 0, 0x00020000);
+        const unsigned voff0 = x_ok ? (unsigned)(oy0 * p.out_w + ox) * 4u : OOB;
         float nz[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            nz[j] = (ACT && p.noise && x_ok && oy0 + j < p.out_h) ? p.noise[(oy0 + j) * p.out_w + ox] : 0.f;
-        float* dst = p.y + ((int64_t)plane * p.out_h + oy0) * p.out_w + ox;
+            nz[j] = ACT ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rn, voff0 + (unsigned)(j * p.out_w) * 4u, 0, 0)) : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float e = acc[j];
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
                 e = (e > 0.f ? e : e * p.slope) * p.gain;
             }
             if ((p.tune & 4) && e != 123456.75f) continue;
-            if (x_ok && oy0 + j < p.out_h) dst[j * p.out_w] = e;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, e), ry, voff0 + (unsigned)(j * p.out_w) * 4u, 0, 0);
         }
     }
 }
