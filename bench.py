@@ -128,8 +128,10 @@ def cpu_baseline(size):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: ~0.7 s of warm-up (a fresh box needs that long to bring the GPU out of its idle clocks: 3 warm-up steps
+    # measured 131 images/s as the first process on a box, 25 measured 142) and ~0.6 s timed
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--batch", type=int, default=4, help="latents per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--clip-backend", default="hip", choices=["hip", "torch"])
