@@ -54,7 +54,7 @@ struct ConvParams {
     int ph, pw, plane;
     unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
     int border_wgs, groups_row, groups_col;  // UP: leading workgroups that compute the last row / column
-    int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop
+    int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop, bit2 = stage only the first chunk, bit5 = no UP border
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
 };
 
@@ -184,8 +184,6 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
     const int o = o_chunk * OL + ol;
     const bool ov = o < p.N;
     // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
-    const int64_t tap_stride = 2 * (int64_t)p.N * 4;
-    const int64_t t0 = (is_row ? 6 : 2) * tap_stride, t1 = (is_row ? 7 : 5) * tap_stride, t2 = 8 * tap_stride;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // unconditional loads at clamped positions (masked afterwards) so that the channel loop can be batched:
     // 4 channels = 36 independent loads in flight per thread instead of one dependent round trip per channel
@@ -197,29 +195,46 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
         msk[t] = (v >= 0 && v < L) ? 1.f : 0.f;
         xoff[t] = fixed + (int64_t)(v < 0 ? 0 : (v >= L ? L - 1 : v)) * stride;
     }
-    const int kper = (((p.K + KG - 1) / KG) + 3) & ~3;
-    const int i_lo = kg * kper, i_hi = (i_lo + kper < p.K) ? i_lo + kper : p.K;
+    // The K reduction runs over 8-channel groups: the packed weights hold the 4 channels {8kc + 2c + h, c = 0..3} of one
+    // (tap, h, o) as ONE float4, so a step takes 6 float4 weight loads (the per-channel form read one float of each float4:
+    // a quarter of every line fetched) and 40 activation loads, all in flight together.
+    const int groups8 = (p.K + 7) >> 3;                            // 8-channel groups: both halves (8 channels) per step
+    const int gper = (groups8 + KG - 1) / KG;
+    const int g_lo = kg * gper, g_hi = (g_lo + gper < groups8) ? g_lo + gper : groups8;
     const float* xb = p.x + (int64_t)b * p.K * in_plane;
-    const float* wb = p.wp + (int64_t)(ov ? o : 0) * 4;  // packed [K/8][9][2][N][4]
-    for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
-        float xv[4][5], wv[4][3], sv[4];
+    const float4* wb4 = reinterpret_cast<const float4*>(p.wp) + (ov ? o : 0);  // packed [K/8][9][2][N] float4
+    const int64_t tap4 = 2 * (int64_t)p.N;                         // float4s per tap
+    const int64_t u0 = (is_row ? 6 : 2) * tap4, u1 = (is_row ? 7 : 5) * tap4, u2 = 8 * tap4;
+    for (int kc = g_lo; kc < g_hi; ++kc) {
+        float4 w0[2], w1[2], w2[2];
+        float xv[8][5], sv[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = (i0 + c < p.K) ? i0 + c : p.K - 1;
-            sv[c] = (i0 + c < i_hi) ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + i] : 1.f) : 0.f;
+        for (int hh = 0; hh < 2; ++hh) {  // every load of the step is issued before the first use: one round trip per 8 channels
+            const float4* wq = wb4 + (int64_t)kc * 9 * tap4 + (int64_t)hh * p.N;
+            w0[hh] = wq[u0], w1[hh] = wq[u1], w2[hh] = wq[u2];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) xv[c][t] = xb[(int64_t)i * in_plane + xoff[t]];
-            const float* wq = wb + (int64_t)(i >> 3) * 9 * 2 * p.N * 4 + (int64_t)(i & 1) * p.N * 4 + ((i & 7) >> 1);
-            wv[c][0] = wq[t0], wv[c][1] = wq[t1], wv[c][2] = wq[t2];
+            for (int c = 0; c < 4; ++c) {
+                const int i = 8 * kc + 2 * c + hh;
+                const int ic = i < p.K ? i : p.K - 1;
+                sv[hh * 4 + c] = i < p.K ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + ic] : 1.f) : 0.f;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) xv[hh * 4 + c][t] = xb[(int64_t)ic * in_plane + xoff[t]];
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int hh = 0; hh < 2; ++hh) {
+            const float wa[4] = {w0[hh].x, w0[hh].y, w0[hh].z, w0[hh].w}, wbv[4] = {w1[hh].x, w1[hh].y, w1[hh].z, w1[hh].w},
+                        wc[4] = {w2[hh].x, w2[hh].y, w2[hh].z, w2[hh].w};
 #pragma unroll
-            for (int t = 0; t < 5; ++t) xv[c][t] *= sv[c] * msk[t];
+            for (int c = 0; c < 4; ++c) {
+                float* xr = xv[hh * 4 + c];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
-                acc[2 * t] += wv[c][0] * xv[c][t + 1] + wv[c][2] * xv[c][t];
-                acc[2 * t + 1] += wv[c][1] * xv[c][t + 1];
+                for (int t = 0; t < 5; ++t) xr[t] *= sv[hh * 4 + c] * msk[t];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
+                    acc[2 * t] += wa[c] * xr[t + 1] + wc[c] * xr[t];
+                    acc[2 * t + 1] += wbv[c] * xr[t + 1];
+                }
             }
         }
     }
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     int bid = blockIdx.x;
     if (is_up(MODE)) {
         if (bid < p.border_wgs) {  // uniform per workgroup
+            if (p.tune_skip & 32) return;  // tuning aid: price the border workgroups
             if (p.N >= 64) upconv_border<64, NT>(p, smem, bid);
             else upconv_border<32, NT>(p, smem, bid);
             return;
