@@ -96,9 +96,11 @@ struct Chunk {
 
 // One K-chunk of MFMAs for a wave.  LDS holds, per 8-channel sub-chunk, ws[slot][h][TN] and xs[h][plane] as float4
 // (.x.y.z.w = channel pairs c = 0..3 of lane-half h), so each b128 read feeds 4 MFMAs.
-template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX>
+// `hook(pos)` is called after the MFMAs of tap slot 0 (pos 0) and of the middle tap slot (pos 1) of the first sub-chunk:
+// the caller issues the NEXT chunk's buffer loads there, in the shadow of the matrix pipe.
+template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX, typename Hook>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4* ws, const float4* xs, int a_base,
-                                           const int (&base)[NPB], int pw, int plane) {
+                                           const int (&base)[NPB], int pw, int plane, Hook hook) {
     using T = Taps<MODE, PY, PX>;
     if constexpr (MODE == CONV_UPALL) {
         constexpr int NPP = NPB / 4;  // pixel blocks per phase
@@ -126,6 +128,8 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4
                         a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].z, bv[off][pb].z, a, 0, 0, 0);
                         a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].w, bv[off][pb].w, a, 0, 0, 0);
                     }
+                if (sub == 0 && slot == 0) hook(0);
+                if (sub == 0 && slot == 4) hook(1);
             }
         }
         return;
@@ -153,6 +157,9 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4
                     acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].z, bv[pb].z, acc[ob][pb], 0, 0, 0);
                     acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].w, bv[pb].w, acc[ob][pb], 0, 0, 0);
                 }
+            if (sub == 0 && slot == 0) hook(0);
+            if (sub == 0 && slot == T::N / 2 && T::N > 1) hook(1);
+            if (sub == 0 && slot == 0 && T::N == 1) hook(1);
         }
     }
 }
@@ -429,9 +436,14 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                 __syncthreads();  // everyone finished reading the previous chunk
                 commit();
                 __syncthreads();
-                if (k0 + KCP < k_hi) prefetch(k0 + KCP);
             }
-            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane);
+            // the next chunk's loads are issued from inside the MFMA stream; the two waves that share a SIMD (w, w+4 in a
+            // 512-thread workgroup) do it at different taps so that one of them always feeds the matrix pipe
+            const bool do_pf = k0 + KCP < k_hi && !(p.tune_skip & 4);
+            const int my_pos = (NT == 512) ? (wave >> 2) : 0;
+            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane, [&](int pos) __attribute__((always_inline)) {
+                if (do_pf && pos == my_pos) prefetch(k0 + KCP);
+            });
         }
     };
     using I0 = std::integral_constant<int, 0>;
