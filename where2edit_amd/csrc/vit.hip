@@ -75,30 +75,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     // Branch-free: out-of-range ROWS / COLUMNS are clamped to a valid one (they only feed accumulator rows / columns
     // that are never stored); an out-of-range K position is read from a clamped address and masked at the LDS write.
     const int s_row = tid >> 4, s_l = tid & 15;
+    // Buffer loads: descriptor per operand + a per-thread byte offset computed once + the K position as the scalar
+    // offset -- no per-step address arithmetic.  Rows past M / N (and, for a [K,N] B, k-rows past K) fall past the
+    // descriptor and read 0.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), (short)0,
+                                                                        (int)((unsigned)p.m * (unsigned)p.lda * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.b), (short)0, (int)((unsigned)(TRANS_B ? p.n : p.k) * (unsigned)p.ldb * 4u), 0x00020000);
+    unsigned aoff[GBM / 16], boff[4];
+#pragma unroll
+    for (int it = 0; it < GBM / 16; ++it) aoff[it] = (unsigned)((m0 + s_row + 16 * it) * p.lda + 4 * s_l) * 4u;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        boff[it] = TRANS_B ? (unsigned)((n0 + s_row + 16 * it) * p.ldb + 4 * s_l) * 4u
+                           : (unsigned)((8 * (s_row >> 1) + (s_row & 1) + 2 * it) * p.ldb + n0 + 4 * s_l) * 4u;
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) __attribute__((always_inline)) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
     auto prefetch = [&](int k0, GemmRegs& R) __attribute__((always_inline)) {
         const int kk = k0 + 4 * s_l;
-        const bool k_ok = kk < p.k;
-        const int kc = k_ok ? kk : 0;
-        R.ka = k_ok ? 0xffffffffu : 0u;
+        R.ka = kk < p.k ? 0xffffffffu : 0u;  // a K position past the row's end would read the next row: masked at the LDS write
+        const unsigned soff = (unsigned)k0 * 4u;
 #pragma unroll
-        for (int it = 0; it < GBM / 16; ++it) {
-            const int row = m0 + s_row + 16 * it;
-            R.a[it] = *reinterpret_cast<const float4*>(p.a + (int64_t)(row < p.m ? row : p.m - 1) * p.lda + kc);
-        }
+        for (int it = 0; it < GBM / 16; ++it) R.a[it] = ld4(ra, aoff[it], soff);
         if (TRANS_B) {
 #pragma unroll
-            for (int it = 0; it < GBN / 16; ++it) {
-                const int row = n0 + s_row + 16 * it;
-                R.b[it] = *reinterpret_cast<const float4*>(p.b + (int64_t)(row < p.n ? row : p.n - 1) * p.ldb + kc);
-            }
+            for (int it = 0; it < GBN / 16; ++it) R.b[it] = ld4(rb, boff[it], soff);
         } else {
-            const int kb = k0 + 8 * (s_row >> 1) + (s_row & 1);
-            const int col = n0 + 4 * s_l < p.n ? n0 + 4 * s_l : 0;
+            const unsigned soffb = (unsigned)k0 * (unsigned)p.ldb * 4u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool kq_ok = kb + 2 * q < p.k;
-                R.kb[q] = kq_ok ? 0xffffffffu : 0u;
-                R.b[q] = *reinterpret_cast<const float4*>(p.b + (int64_t)(kq_ok ? kb + 2 * q : 0) * p.ldb + col);
+                R.kb[q] = 0xffffffffu;  // k-rows past K are past the descriptor: zeros
+                R.b[q] = ld4(rb, boff[q], soffb);
             }
         }
     };
@@ -151,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     // written to the stage during the second half of step t-1 -- a step and a half of MFMAs to cover the round trip.
     // `Rload` = the set to refill with step t+2 (it held step t, already in LDS), `Rnext` = the set holding step t+1.
     auto step = [&](int k0, int stage, GemmRegs& Rload, const GemmRegs& Rnext) __attribute__((always_inline)) {
-        prefetch(k0 + 2 * GBK < k_hi ? k0 + 2 * GBK : k_lo, Rload);
         const float4* As4 = gsm + stage * STAGE;
         const float4* Bs4 = As4 + (GBK / 4) * GPA;
         float4* An = gsm + (stage ^ 1) * STAGE;  // the other stage: every wave left it at the barrier that ended the last step
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             acc4[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc4[1], 0, 0, 0);
             acc4[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc4[2], 0, 0, 0);
             acc4[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc4[3], 0, 0, 0);
+            if (g == 0) prefetch(k0 + 2 * GBK < k_hi ? k0 + 2 * GBK : k_lo, Rload);  // in the shadow of the first MFMAs
             if (g >= GBK / 16 && has_next) {  // second half: step t+1 goes to the other stage, two pieces per MFMA group
 #pragma unroll
                 for (int q = 0; q < NPIECE / 4; ++q) commit_piece((g - GBK / 16) * (NPIECE / 4) + q, Rnext, An, Bn);
@@ -454,6 +464,8 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     W2E_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "gemm: operands must be 16-byte aligned");
     W2E_REQUIRE(!(a_gelu && !trans_b), "gemm: the QuickGELU prologue is implemented for the [N,K] form only");
     if (m == 0) return 0;
+    W2E_REQUIRE((int64_t)m * lda * 4 < ((int64_t)1 << 32) && (int64_t)(trans_b ? n : k) * ldb * 4 < ((int64_t)1 << 32),
+                "gemm: an operand exceeds 4 GB");
     hipStream_t s = (hipStream_t)stream;
     // Small-M GEMMs (M = 50*batch) leave most CUs idle with one workgroup per 64x64 tile and make every wave a
     // K/2-long dependent MFMA chain: split K over blockIdx.z (fp32 atomics onto a zeroed C) until the grid fills the chip.
