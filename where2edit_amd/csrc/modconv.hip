@@ -721,7 +721,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const size_t lds_c = up ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep * ph * pw)
                                 : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * ph * pw);
         if (lds_c > 150 * 1024) continue;
-        if (mode == W2E_CONV_DOWN && max_patch_slots(mode, tm, nt) * (cfgs[c].nob * cfgs[c].npb >= 8 ? 2 : 1) > 5) continue;  // prefetch registers: 8 channels x slots
+        if (mode == W2E_CONV_DOWN && max_patch_slots(mode, tm, nt) > 5) continue;  // prefetch registers: 8 channels x slots
         if (ph * pw > nt * max_patch_slots(mode, tm, nt)) continue;  // register-prefetch slots per thread
         const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
         const double waves_per_simd = nt / 256.0;
@@ -738,7 +738,11 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
                 const double per_cu = ceil(4.0 * tiles * sp / 256.0) / 4.0;  // tile-slices (sets of 4 phases) per CU
                 cost = per_cu * ((9.0 * unit + 4.0 * t_stage) / sp + 16000.0) + (4.0 * tiles * sp < 1024.0 ? 1.75 * unit / sp : 0.0);
             } else {
-                cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + t_stage) / sp + 4000.0);  // + prologue/epilogue per workgroup
+                // + prologue/epilogue per workgroup.  With <= 4 chunks per tile (the K = 32 layers) those fixed costs are a
+                // third of a tile, and two co-resident 256-thread workgroups hide part of each other's (measured: 32x512
+                // tiles beat 32x1024 by 6 % on the 1024^2 layer, not on the deeper ones)
+                const double fixed = (nt == 256 && k_ch <= 4 * kc) ? 0.4 : 1.0;
+                cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + fixed * t_stage) / sp + fixed * 4000.0);
             }
             if (sp > 1) {  // memset + (with act) the separate bias/act pass + the fp32 atomics: ~120 cycles per 256-B
                            // wave-instruction per CU (MI355X_MICROARCH.md, global float atomics)
