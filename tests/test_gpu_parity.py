@@ -462,3 +462,46 @@ def test_batched_style_affines_match_per_layer_path():
         assert_close(a, b, 1e-5, "style")
     assert_close(img_a, img_b, 1e-4, "image")
     assert_grad_close(gw_a, gw_b, "w+ grad")
+
+
+@pytest.mark.parametrize("b,k,n,h,w", [(3, 20, 36, 20, 36), (2, 7, 5, 7, 19), (1, 64, 96, 33, 17), (5, 8, 8, 64, 4),
+                                        (2, 96, 40, 48, 80), (1, 130, 70, 16, 24)])
+def test_modconv_abi_non_square_and_ragged_channels(b, k, n, h, w):
+    """w2e_modconv3x3 through the C ABI on shapes the generator never produces -- H != W, channel counts that are not
+    multiples of 8 / 32, odd sizes, batch 1..5 -- in all three modes, with the fused activation and the dot epilogue,
+    against torch's float64 convolutions of the same shared-weight formula."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(1000 * k + n)
+    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+    scale = (k * 9) ** -0.5
+    x = torch.randn(b, k, h, w, generator=g).to(DEV)
+    s_in = (torch.randn(b, k, generator=g) * 0.3 + 1).to(DEV)
+    s_out = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    wd, xd = wt.double() * scale, x.double() * s_in.double()[:, :, None, None]
+    so = s_out.double()[:, :, None, None]
+    # SAME, plain / fused activation / dot epilogue
+    ref = F.conv2d(xd, wd, padding=1) * so
+    fwd = K.conv_pack(wt, scale, False, False)
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
+    assert_close(y, ref, FWD_TOL, "same")
+    noise = torch.randn(1, 1, h, w, generator=g).to(DEV)
+    nw, bias = torch.randn(1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    pre = ref + nw.double() * noise.double() + bias.double()[None, :, None, None]
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
+    assert_close(y, F.leaky_relu(pre, 0.2) * 2 ** 0.5, FWD_TOL, "same + act")
+    dw = torch.randn(b, n, h, w, generator=g).to(DEV)
+    y, dot = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, dot_with=dw)
+    # dot_out[b,o] = sum_p (unscaled accumulator) * dot_with  (the epilogue multiplies by out_scale only on the stored y)
+    assert_close(y, ref, FWD_TOL, "same (dot epilogue) y")
+    assert_close(dot, (ref / so * dw.double()).sum((2, 3)), 5e-4, "dot_out")
+    # UP: conv_transpose2d stride 2 -> T (2h+1) x (2w+1), phase-planar
+    wt_t = torch.randn(k, n, 3, 3, generator=g).to(DEV)  # conv_transpose weight layout [in, out, 3, 3]
+    up = K.conv_pack(wt_t.permute(1, 0, 2, 3).contiguous(), scale, False, False)
+    t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
+    ref_t = F.conv_transpose2d(xd, wt_t.double() * scale, stride=2) * so
+    assert_close(K.unplanar(t, w), ref_t, FWD_TOL, "up")
+    # DOWN: stride-2 conv of a (2h+1) x (2w+1) input
+    xb = torch.randn(b, k, 2 * h + 1, 2 * w + 1, generator=g).to(DEV)
+    y, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
+    assert_close(y, F.conv2d(xb.double() * s_in.double()[:, :, None, None], wd, stride=2) * so, FWD_TOL, "down")
