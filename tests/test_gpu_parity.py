@@ -501,6 +501,19 @@ def test_modconv_abi_non_square_and_ragged_channels(b, k, n, h, w):
     t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
     ref_t = F.conv_transpose2d(xd, wt_t.double() * scale, stride=2) * so
     assert_close(K.unplanar(t, w), ref_t, FWD_TOL, "up")
+    if w >= 16:  # the 4x4 blur reading the phase-planar T directly (+ fused noise/bias/lrelu), and its plain-layout adjoint
+        k4 = cu(seeded.fir_kernel(gain=4.0))
+        noise2 = torch.randn(1, 1, 2 * h, 2 * w, generator=g).to(DEV)
+        blurred = O.upfirdn2d(ref_t.float().cpu(), seeded.fir_kernel(gain=4.0), pad=(1, 1)).double().to(DEV)
+        pre2 = blurred + nw.double() * noise2.double() + bias.double()[None, :, None, None]
+        got = K._upfirdn2d_raw(t, k4, 2 * h, 2 * w, 1, 1, 1, 1, True, act=(None, noise2, nw, bias), planar_hw=(2 * h + 1, 2 * w + 1))
+        assert_close(got, F.leaky_relu(pre2, 0.2) * 2 ** 0.5, FWD_TOL, "planar blur + act")
+        gq = torch.randn(b, n, 2 * h, 2 * w, generator=g).to(DEV)
+        adj = K._upfirdn2d_raw(gq, k4, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
+        tq = torch.randn(b, n, 2 * h + 1, 2 * w + 1, generator=g).to(DEV)
+        fwd_q = K._upfirdn2d_raw(tq, k4, 2 * h, 2 * w, 1, 1, 1, 1, True)
+        lhs, rhs = (fwd_q.double() * gq.double()).sum(), (tq.double() * adj.double()).sum()
+        assert abs(lhs - rhs) <= 1e-5 * (fwd_q.double().abs() * gq.double().abs()).sum(), "blur adjoint"
     # DOWN: stride-2 conv of a (2h+1) x (2w+1) input
     xb = torch.randn(b, k, 2 * h + 1, 2 * w + 1, generator=g).to(DEV)
     y, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
