@@ -25,6 +25,10 @@ extern "C" {
  * lda/ldb/ldc are row strides in elements. */
 int w2e_gemm(const float* a, const float* b, float* c, int m, int n, int k, int lda, int ldb, int ldc, int trans_b,
              int a_gelu, const float* bias, const float* residual, const float* gelu_grad_aux, void* stream);
+/* The same with c_is_zero != 0: the caller guarantees C holds zeros, so a split-K launch (the skinny N = 768 shapes) adds
+ * onto it without the memset of its own -- a transformer pass zero-fills one arena for all such outputs at once. */
+int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int n, int k, int lda, int ldb, int ldc, int trans_b,
+                int a_gelu, const float* bias, const float* residual, const float* gelu_grad_aux, int c_is_zero, void* stream);
 
 /* LayerNorm over the last dim (eps inside rsqrt), rows x dim.  fwd saves mean and rstd (rows each). */
 int w2e_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -5,6 +5,7 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 PROTOS = {
     "w2e_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "w2e_gemm_ex": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "w2e_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "w2e_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "w2e_layernorm_bwd_add": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),

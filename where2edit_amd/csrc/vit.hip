@@ -454,9 +454,9 @@ static int set_big_lds(const void* fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
 }
 
-extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, int k, int lda, int ldb, int ldc,
-                        int trans_b, int a_gelu, const float* bias, const float* residual, const float* gelu_grad_aux,
-                        void* stream) {
+extern "C" int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int n, int k, int lda, int ldb, int ldc,
+                           int trans_b, int a_gelu, const float* bias, const float* residual, const float* gelu_grad_aux,
+                           int c_is_zero, void* stream) {
     W2E_REQUIRE(a && b && c, "gemm: null tensor");
     W2E_REQUIRE(m >= 0 && n > 0 && k > 0, "gemm: bad dims %d %d %d", m, n, k);
     W2E_REQUIRE((k & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0, "gemm: K, lda, ldb must be multiples of 4");
@@ -487,7 +487,7 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     }
     const int k_per = (int)(ceil_div(ceil_div(k, splits), 2 * GBK) * 2 * GBK);  // an even number of 64-deep steps
     splits = (int)ceil_div(k, k_per);
-    if (splits > 1 && hipMemsetAsync(c, 0, sizeof(float) * (size_t)m * n, s) != hipSuccess) {
+    if (splits > 1 && !c_is_zero && hipMemsetAsync(c, 0, sizeof(float) * (size_t)m * n, s) != hipSuccess) {
         set_error("gemm: memset failed");
         return 2;
     }
@@ -506,6 +506,12 @@ extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, 
     }
     W2E_LAUNCH_CHECK("gemm");
     return 0;
+}
+
+extern "C" int w2e_gemm(const float* a, const float* b, float* c, int m, int n, int k, int lda, int ldb, int ldc,
+                        int trans_b, int a_gelu, const float* bias, const float* residual, const float* gelu_grad_aux,
+                        void* stream) {
+    return w2e_gemm_ex(a, b, c, m, n, k, lda, ldb, ldc, trans_b, a_gelu, bias, residual, gelu_grad_aux, 0, stream);
 }
 
 extern "C" int w2e_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -4,6 +4,8 @@ and `vision_forward`, the HIP execution of clip_vit.VisionTransformer.forward.
 
 CLIP is a frozen critic here (criteria/clip_loss.py builds it once and never optimises it), so the
 Functions return input gradients only; asking for a weight gradient raises."""
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -16,14 +18,15 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _gemm(a, b, trans_b, bias=None, residual=None, a_gelu=False, gelu_grad_aux=None):
-    """C[M,N] = epi(pro(A) x B): B is [N,K] (trans_b) or [K,N]."""
+def _gemm(a, b, trans_b, bias=None, residual=None, a_gelu=False, gelu_grad_aux=None, out=None):
+    """C[M,N] = epi(pro(A) x B): B is [N,K] (trans_b) or [K,N].  `out`: a ZERO-filled [M,N] buffer to write into (a slice
+    of a per-pass arena: split-K launches then skip their own memset)."""
     m, k = a.shape
     n = b.shape[0] if trans_b else b.shape[1]
-    c = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    c = out if out is not None else torch.empty((m, n), device=a.device, dtype=torch.float32)
     sp = profiling.span("vit_gemm", 2.0 * m * n * k)
-    call("w2e_gemm", ptr(a), ptr(b), ptr(c), m, n, k, a.stride(0), b.stride(0), n, int(trans_b), int(a_gelu),
-         ptr(bias), ptr(residual), ptr(gelu_grad_aux), stream_ptr())
+    call("w2e_gemm_ex", ptr(a), ptr(b), ptr(c), m, n, k, a.stride(0), b.stride(0), n, int(trans_b), int(a_gelu),
+         ptr(bias), ptr(residual), ptr(gelu_grad_aux), int(out is not None), stream_ptr())
     if sp is not None:
         sp.end()
     return c
@@ -155,7 +158,7 @@ class _ResBlock(torch.autograd.Function):
     the residual joins of the backward ride in the LayerNorm-backward kernel instead of two extra `add` launches."""
 
     @staticmethod
-    def forward(ctx, x, heads, eps1, eps2, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b):
+    def forward(ctx, x, heads, eps1, eps2, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b, arena):
         _frozen(ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b)
         b, l, dim = x.shape
         if dim != heads * 64:
@@ -165,12 +168,15 @@ class _ResBlock(torch.autograd.Function):
         qkv = _gemm(y1, in_w, True, bias=in_b)
         att = torch.empty((b * l, dim), device=x.device, dtype=torch.float32)
         call("w2e_attn_fwd", ptr(qkv), ptr(att), b, l, heads, stream_ptr())
-        x_mid = _gemm(att, out_w, True, bias=out_b, residual=x2)
+        # the two N = width outputs are split-K launches: they land in zero-filled slices of the pass's arena
+        z = arena.take(2, b * l, dim) if arena is not None else (None, None)
+        x_mid = _gemm(att, out_w, True, bias=out_b, residual=x2, out=z[0])
         y2, mean2, rstd2 = _ln_fwd(x_mid, ln2_w, ln2_b, eps2)
         h = _gemm(y2, fc_w, True, bias=fc_b)
-        out = _gemm(h, proj_w, True, bias=proj_b, residual=x_mid, a_gelu=True)
+        out = _gemm(h, proj_w, True, bias=proj_b, residual=x_mid, a_gelu=True, out=z[1])
         ctx.save_for_backward(x2, mean1, rstd1, qkv, x_mid, mean2, rstd2, h, ln1_w, in_w, out_w, ln2_w, fc_w, proj_w)
         ctx.geom = (b, l, dim, heads)
+        ctx.arena = arena
         return out.reshape(b, l, dim)
 
     @staticmethod
@@ -181,25 +187,56 @@ class _ResBlock(torch.autograd.Function):
         rows = b * l
         g = _c(gout).reshape(rows, dim)
         gh = _gemm(g, proj_w, False, gelu_grad_aux=h)           # through c_proj and QuickGELU'
-        gy2 = _gemm(gh, fc_w, False)                            # through c_fc
+        z = ctx.arena.take_bwd(3, rows, dim) if ctx.arena is not None else (None, None, None)
+        gy2 = _gemm(gh, fc_w, False, out=z[0])                  # through c_fc
         g_mid = torch.empty_like(x_mid)                         # through ln_2, + the residual branch
         call("w2e_layernorm_bwd_add", ptr(gy2), ptr(x_mid), ptr(ln2_w), ptr(mean2), ptr(rstd2), ptr(g), ptr(g_mid), rows, dim,
              stream_ptr())
-        ga = _gemm(g_mid, out_w, False)                         # through out_proj
+        ga = _gemm(g_mid, out_w, False, out=z[1])               # through out_proj
         gqkv = torch.empty_like(qkv)
         call("w2e_attn_bwd", ptr(qkv), ptr(ga), ptr(gqkv), b, l, heads, stream_ptr())
-        gy1 = _gemm(gqkv, in_w, False)                          # through in_proj
+        gy1 = _gemm(gqkv, in_w, False, out=z[2])                # through in_proj
         gx = torch.empty_like(x2)                               # through ln_1, + the residual branch
         call("w2e_layernorm_bwd_add", ptr(gy1), ptr(x2), ptr(ln1_w), ptr(mean1), ptr(rstd1), ptr(g_mid), ptr(gx), rows, dim,
              stream_ptr())
-        return (gx.reshape(b, l, dim),) + (None,) * 15
+        return (gx.reshape(b, l, dim),) + (None,) * 16
 
 
-def resblock_forward(blk, x, heads):
+class _ZeroArena:
+    """Zero-filled scratch for the split-K GEMM outputs of one transformer pass: ONE fill launch for all blocks of the
+    forward (and one more, on first use, for the backward) instead of a memset per GEMM."""
+
+    def __init__(self, n_blocks, device):
+        self.n_blocks, self.device = n_blocks, device
+        self.fwd = self.bwd = None
+        self.i = self.j = 0
+
+    def _take(self, buf, idx, count, rows, dim):
+        if idx >= self.n_blocks:  # a second backward through the same graph: its buffers must be zero again
+            return tuple(torch.zeros((rows, dim), device=self.device, dtype=torch.float32) for _ in range(count))
+        return tuple(buf[idx * count + c] for c in range(count))
+
+    def take(self, count, rows, dim):
+        if self.fwd is None:
+            self.fwd = torch.zeros((self.n_blocks * count, rows, dim), device=self.device, dtype=torch.float32)
+        out = self._take(self.fwd, self.i, count, rows, dim)
+        self.i += 1
+        return out
+
+    def take_bwd(self, count, rows, dim):
+        if self.bwd is None:
+            self.bwd = torch.zeros((self.n_blocks * count, rows, dim), device=self.device, dtype=torch.float32)
+        out = self._take(self.bwd, self.j, count, rows, dim)
+        self.j += 1
+        return out
+
+
+def resblock_forward(blk, x, heads, arena=None):
     """ResidualAttentionBlock: x += out_proj(attn(in_proj(ln_1 x))); x += c_proj(QuickGELU(c_fc(ln_2 x)))."""
     return _ResBlock.apply(x, heads, blk.ln_1.eps, blk.ln_2.eps, blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_weight,
                            blk.attn.in_proj_bias, blk.attn.out_proj.weight, blk.attn.out_proj.bias, blk.ln_2.weight,
-                           blk.ln_2.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+                           blk.ln_2.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias,
+                           arena)
 
 
 def vision_forward(vit, image):
@@ -212,7 +249,8 @@ def vision_forward(vit, image):
     b = x.shape[0]
     x = torch.cat([vit.class_embedding.view(1, 1, width).expand(b, 1, width), x], dim=1) + vit.positional_embedding
     x = layer_norm(x, vit.ln_pre)
+    arena = None if os.environ.get("W2E_TUNE_NO_ARENA") else _ZeroArena(len(vit.transformer.resblocks), x.device)
     for blk in vit.transformer.resblocks:
-        x = resblock_forward(blk, x, vit.heads)
+        x = resblock_forward(blk, x, vit.heads, arena)
     x = layer_norm(x[:, 0, :], vit.ln_post)
     return linear(x, vit.proj.t())  # [B,768] x [768,512]
