@@ -56,6 +56,7 @@ struct ConvParams {
     int border_wgs, groups_row, groups_col;  // UP: leading workgroups that compute the last row / column
     int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop, bit2 = stage only the first chunk, bit5 = no UP border
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
+    unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
 };
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
@@ -98,9 +99,13 @@ struct Chunk {
 // (.x.y.z.w = channel pairs c = 0..3 of lane-half h), so each b128 read feeds 4 MFMAs.
 // `hook(pos)` is called after the MFMAs of tap slot 0 (pos 0) and of the middle tap slot (pos 1) of the first sub-chunk:
 // the caller issues the NEXT chunk's buffer loads there, in the shadow of the matrix pipe.
-template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX, typename Hook>
+__device__ __forceinline__ void mul4(float4& a, const float4& s) { a.x *= s.x, a.y *= s.y, a.z *= s.z, a.w *= s.w; }
+
+// SCALED (the LDS-DMA pipeline, where the staged activations are raw): the per-sample modulation s4[sub] = in_scale of the
+// lane-half's 4 channels is applied to the fragments after the LDS read -- to the operand with fewer fragments per chunk.
+template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX, bool SCALED, typename Hook>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4* ws, const float4* xs, int a_base,
-                                           const int (&base)[NPB], int pw, int plane, Hook hook) {
+                                           const int (&base)[NPB], int pw, int plane, const float4 (&s4)[KCP / 8], Hook hook) {
     using T = Taps<MODE, PY, PX>;
     if constexpr (MODE == CONV_UPALL) {
         constexpr int NPP = NPB / 4;  // pixel blocks per phase
@@ -110,7 +115,10 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4
 #pragma unroll
             for (int off = 0; off < 4; ++off)
 #pragma unroll
-                for (int pb = 0; pb < NPP; ++pb) bv[off][pb] = xs[base[pb] + sub * 2 * plane - (off >> 1) * pw - (off & 1)];
+                for (int pb = 0; pb < NPP; ++pb) {
+                    bv[off][pb] = xs[base[pb] + sub * 2 * plane - (off >> 1) * pw - (off & 1)];
+                    if (SCALED) mul4(bv[off][pb], s4[sub]);
+                }
 #pragma unroll
             for (int slot = 0; slot < 9; ++slot) {
                 const int ta = slot / 3, tb = slot % 3;
@@ -142,7 +150,10 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4
             const int ta = T::ta(slot), tb = T::tb(slot);
             float4 av[NOB], bv[NPB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (sub * T::N + slot) * 2 * TN + ob * 32];
+            for (int ob = 0; ob < NOB; ++ob) {
+                av[ob] = ws[a_base + (sub * T::N + slot) * 2 * TN + ob * 32];
+                if (SCALED) mul4(av[ob], s4[sub]);
+            }
             int toff;
             if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * pw - (tb >> 1);
             else toff = ta * pw + tb;
@@ -266,7 +277,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
     }
 }
 
-template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
+template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, bool DMA>
 __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
     constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
     constexpr int TN = 32 * NOB * WO;
@@ -299,6 +310,10 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     bid /= p.splits;
     const int k_lo = ks * p.k_per;
     const int k_hi = (p.tune_skip & 2) ? k_lo : ((k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K);
+    if (p.stamps && tid == 0) {
+        p.stamps[4 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -441,14 +456,110 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
             // 512-thread workgroup) do it at different taps so that one of them always feeds the matrix pipe
             const bool do_pf = k0 + KCP < k_hi && !(p.tune_skip & 4);
             const int my_pos = (NT == 512) ? (wave >> 2) : 0;
-            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX>(acc, ws, xs, a_base, base, p.pw, p.plane, [&](int pos) __attribute__((always_inline)) {
+            const float4 no_scale[KCP / 8] = {};
+            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX, false>(acc, ws, xs, a_base, base, p.pw, p.plane, no_scale, [&](int pos) __attribute__((always_inline)) {
                 if (do_pf && pos == my_pos) prefetch(k0 + KCP);
+            });
+        }
+    };
+
+    // ---- LDS-DMA pipeline (DMA = true; SAME / all-phase UP / DOWN): `buffer_load ... lds` writes the next chunk straight
+    // into the OTHER of two LDS stages while this chunk's MFMAs run -- no staging registers, no LDS write pass, one barrier
+    // per chunk.  A DMA wave-instruction fills 64 consecutive LDS dwords (b32) or float4s (b128) from per-lane addresses, so
+    // the LDS image keeps its MFMA order and the lanes pick the matching global elements: for the patch, lane 4i+c of an
+    // instruction fetches channel 2c+h of pixel i (the float4 of a pixel = 4 lanes); for the weights one lane = one packed
+    // float4.  Halo pixels outside the image, channels >= K and weight groups past K carry out-of-range offsets: the
+    // hardware writes zeros.  The activations land unscaled; in_scale is applied to the fragments (mfma_chunk SCALED) from
+    // a per-image table in LDS.  The host pads p.plane to a multiple of 16 pixels so that no instruction straddles planes.
+    auto dma_loop = [&](auto) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) char lds_char;
+        typedef __attribute__((address_space(3))) void lds_void;
+        constexpr int WQ4 = (KC / 8) * 9 * 2 * TN;   // float4s of a staged weight chunk (a multiple of 64)
+        constexpr int WQ = (WQ4 + NT - 1) / NT;
+        constexpr int XT = 4 * MAXX + 1;             // >= ceil(4 * plane / NT), dword slots per thread per (sub, h) plane
+        // the plane holds at least the tile's own pixels (4x that for DOWN): slots below XT_MIN are whole for every wave
+        constexpr int XT_MIN = (MODE == W2E_CONV_DOWN ? 16 : 4) * (32 * NPX * WP) / NT;
+        static_assert(WQ4 % 64 == 0, "whole wave-instructions");
+        const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int plane4 = p.plane * 4;
+        const int stage_floats = WS_FLOATS + (KC / 8) * 2 * plane4;
+        lds_char* const l0 = (lds_char*)smem;
+        float* const stw = smem + 2 * stage_floats;  // in_scale table [ceil(K/8)][2] float4: (g, h).c = channel 8g + 2c + h
+        const float4* const st = reinterpret_cast<const float4*>(stw);
+        const int a_base = half * TN + wo * NOB * 32 + j;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x + (int64_t)b * p.K * in_plane), (short)0, (int)(unsigned)((int64_t)p.K * in_plane * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.wp), (short)0, (int)(((p.K + 7) >> 3) * 9 * 2 * p.N * 16), 0x00020000);
+        unsigned xoff[XT], woff[WQ];
+        const unsigned cplane = (unsigned)(2 * (lane & 3)) * (unsigned)(in_plane * 4);
+#pragma unroll
+        for (int t = 0; t < XT; ++t) {
+            const int idx = (tid + t * NT) >> 2;  // pixel of the padded plane
+            const int py = (int)__umulhi((unsigned)idx, p.pw_magic);
+            const int px = idx - py * p.pw;
+            const int iy = oy0 + py, ix = ox0 + px;
+            const bool inb = idx < patch && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            xoff[t] = inb ? (unsigned)(iy * p.in_w + ix) * 4u + cplane : 0xfffffff0u;
+        }
+        const unsigned wgroup_bytes = 9u * 2u * (unsigned)p.N * 16u;
+#pragma unroll
+        for (int t = 0; t < WQ; ++t) {
+            const int q = tid + t * NT;
+            const int o = q % TN, rh = q / TN;  // rh = (sub*9 + tap)*2 + h
+            const int hh = rh & 1, ss = rh >> 1;
+            const int tap = ss % 9, sub = ss / 9;
+            const int oc = n0 + o < p.N ? n0 + o : p.N - 1;
+            woff[t] = q < WQ4 ? (unsigned)sub * wgroup_bytes + (unsigned)(((tap * 2 + hh) * p.N + oc) * 16) : 0xfffffff0u;
+        }
+        auto issue = [&](int k0, int stage) __attribute__((always_inline)) {
+            lds_char* const lb = l0 + stage * stage_floats * 4;
+            const unsigned wbase = (unsigned)(k0 >> 3) * wgroup_bytes;
+#pragma unroll
+            for (int t = 0; t < WQ; ++t) {
+                const int start = t * NT + swave * 64;
+#if defined(__HIP_DEVICE_COMPILE__)  // (hipcc's host pass rejects the 16-byte form silently and then drops the kernel's host stub)
+                if ((t + 1) * NT <= WQ4 || start < WQ4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lb + start * 16), 16, woff[t], wbase, 0, 0);
+#endif
+            }
+#pragma unroll
+            for (int sh = 0; sh < 2 * (KC / 8); ++sh) {  // the (sub, h) planes of the patch
+                const unsigned soff = (unsigned)(k0 + (sh >> 1) * 8 + (sh & 1)) * (unsigned)(in_plane * 4);
+                lds_char* const xb = lb + (WS_FLOATS + sh * plane4) * 4;
+#pragma unroll
+                for (int t = 0; t < XT; ++t) {
+                    const int start = t * NT + swave * 64;
+                    if (t < XT_MIN || start < plane4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(xb + start * 4), 4, xoff[t], soff, 0, 0);
+                }
+            }
+        };
+        if (k_lo < k_hi) issue(k_lo, 0);
+        for (int e = tid; e < ((p.K + 7) >> 3) * 8; e += NT) {
+            const int ch = 8 * (e >> 3) + 2 * (e & 3) + ((e >> 2) & 1);
+            stw[e] = ch < p.K ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + ch] : 1.f) : 0.f;
+        }
+        const int my_pos = (NT == 512) ? (swave >> 2) : 0;
+        int stage = 0;
+        for (int k0 = k_lo; k0 < k_hi; k0 += KC, stage ^= 1) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of chunk k0 have landed ...
+            __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
+            const float4* wsc = reinterpret_cast<const float4*>(smem + stage * stage_floats);
+            const float4* xsc = wsc + WS_FLOATS / 4;
+            float4 s4[KC / 8];
+#pragma unroll
+            for (int sub = 0; sub < KC / 8; ++sub) s4[sub] = st[((k0 >> 3) + sub) * 2 + half];
+            const bool do_pf = k0 + KC < k_hi;
+            mfma_chunk<MODE, NOB, NPB, KC, TN, 0, 0, true>(acc, wsc, xsc, a_base, base, p.pw, p.plane, s4, [&](int pos) __attribute__((always_inline)) {
+                if (do_pf && pos == my_pos) issue(k0 + KC, stage ^ 1);
             });
         }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    if (MODE == W2E_CONV_UP) {
+    if constexpr (DMA) {
+        static_assert(MODE != W2E_CONV_UP, "the per-phase UP form keeps the register pipeline");
+        dma_loop(0);
+    } else if (MODE == W2E_CONV_UP) {
         switch (phase) {
             case 0: k_loop(I0{}, I0{}); break;
             case 1: k_loop(I0{}, I1{}); break;
@@ -570,6 +681,10 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         __syncthreads();
         if (tid < TN && n0 + tid < p.N) atomicAdd(&p.dot_out[(int64_t)b * p.N + n0 + tid], red[tid]);
     }
+    if (p.stamps && tid == 0) {
+        p.stamps[4 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // weight [cout,cin,3,3] -> wp [ceil(K/8)][9][2][N][4]: element (kc, tap, h, n, c) = scale * W(k = 8*kc + 2*c + h, tap', n)
@@ -598,16 +713,46 @@ struct TileCfg {
     int nob, npb, wo, wp;
 };
 
-template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC>
+template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, bool DMA = false>
 static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {  // dynamic LDS above 64 KB is opt-in per kernel (gfx950: 160 KB per CU)
         static size_t allowed = 0;
         if (lds > allowed &&
-            hipFuncSetAttribute((const void*)modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC>,
+            hipFuncSetAttribute((const void*)modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
             allowed = 150 * 1024;
     }
-    modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC><<<grid, 64 * WO * WP, lds, s>>>(p);
+    modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA><<<grid, 64 * WO * WP, lds, s>>>(p);
+}
+
+// The LDS-DMA pipeline is instantiated for the tiles the high-resolution layers use; other tiles keep the register pipeline.
+static bool dma_has_cfg(bool all_phase, int cfg) {
+    return all_phase ? (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 11)
+                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10);
+}
+
+template <int MODE, int EPI, int KC>
+static bool launch_mode_dma(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    if constexpr (MODE == CONV_UPALL) {
+        switch (cfg) {
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC, true>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
+            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, true>(p, grid, lds, s); return true;
+            case 11: launch_cfg<MODE, EPI, 1, 8, 1, 8, KC, true>(p, grid, lds, s); return true;
+        }
+        return false;
+    } else {
+        switch (cfg) {
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC, true>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
+            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, true>(p, grid, lds, s); return true;
+            case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC, true>(p, grid, lds, s); return true;
+            case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC, true>(p, grid, lds, s); return true;
+        }
+        return false;
+    }
 }
 
 template <int MODE, int EPI, int KC>
@@ -808,10 +953,26 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     p.pw_magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)p.pw + 1);
     W2E_REQUIRE(p.plane < 65536, "modconv3x3: patch too large");
     const int nt_best = 64 * cfg.wo * cfg.wp;
+    // LDS-DMA pipeline (two LDS stages + the in_scale table): where it is instantiated and fits
+    // W2E_TUNE_DMA: 0 never, 1 wherever instantiated; default = where it measured faster (tools/layer_bench.py, batch 4):
+    // the 512-thread 8-accumulator SAME tiles (+1.5-3 %) and the all-phase UP tile 0 (+2 %); not DOWN (-1-2 %), not the
+    // 256-thread 32x512 tile of the 1024^2 layer (two LDS stages leave room for 2 instead of 3 workgroups per CU: -11 %)
+    static const int tune_dma = getenv("W2E_TUNE_DMA") ? atoi(getenv("W2E_TUNE_DMA")) : -1;
+    bool use_dma = false;
+    size_t lds_dma = 0;
+    const bool dma_auto = use_all ? best == 0 : (mode == W2E_CONV_SAME && best <= 2);
+    if ((tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
+        const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
+        lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
+        const int slots = (int)ceil_div(4 * plane16, nt_best);
+        if (lds_dma <= 150 * 1024 && slots <= 4 * max_patch_slots(up ? W2E_CONV_UP : mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
+        if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "  lds-dma pipeline: %s (%zu B LDS, %d slots)\n", use_dma ? "yes" : "no", lds_dma, slots);
+    }
     const int kdeep_best = (up && !use_all && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
     size_t lds = (up && !use_all) ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
                                   : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
+    if (use_dma) lds = lds_dma;
     W2E_REQUIRE(lds <= 150 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
     const int k_gran = use_all ? kc : kc_max;
     p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), k_gran) * k_gran);
@@ -823,13 +984,38 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
+    // tuning aid: W2E_TUNE_CLOCK=1 stamps every workgroup and reports the in-kernel shader clock (s_memtime ticks per
+    // 100 MHz s_memrealtime tick) of every 64th launch -- the DVFS-limited clock is what an MFMA-bound kernel is priced by
+    static const bool tune_clock = getenv("W2E_TUNE_CLOCK") && atoi(getenv("W2E_TUNE_CLOCK"));
+    static unsigned long long* stamp_buf = nullptr;
+    static int64_t stamp_cap = 0, stamp_calls = 0;
+    bool stamped = false;
+    if (tune_clock && (stamp_calls++ & 63) == 63) {
+        if (grid > stamp_cap) {
+            if (stamp_buf) (void)hipFree(stamp_buf);
+            stamp_cap = grid, stamp_buf = nullptr;
+            if (hipMalloc((void**)&stamp_buf, sizeof(unsigned long long) * 4 * (size_t)stamp_cap) != hipSuccess) stamp_buf = nullptr, stamp_cap = 0;
+        }
+        if (stamp_buf && hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * 4 * (size_t)grid, s) == hipSuccess) p.stamps = stamp_buf, stamped = true;
+    }
     if (p.splits > 1 &&
         hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
         return 2;
     }
     bool ok = false;
-    if (mode == W2E_CONV_SAME) {
+    if (use_dma) {
+        if (mode == W2E_CONV_SAME) {
+            if (act && p.splits == 1) ok = launch_mode_dma<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
+            else if (dot_with) ok = launch_mode_dma<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
+            else ok = launch_mode_dma<W2E_CONV_SAME, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+        } else if (up) {
+            ok = launch_mode_dma<CONV_UPALL, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+        } else {
+            if (dot_with) ok = launch_mode_dma<W2E_CONV_DOWN, EPI_DOT, 8>(best, p, (int)grid, lds, s);
+            else ok = launch_mode_dma<W2E_CONV_DOWN, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
+        }
+    } else if (mode == W2E_CONV_SAME) {
         if (act && p.splits == 1) ok = launch_mode<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
         else if (dot_with) ok = launch_mode<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
         else ok = launch_mode<W2E_CONV_SAME, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
@@ -842,6 +1028,24 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     }
     W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
     W2E_LAUNCH_CHECK("modconv3x3");
+    if (stamped) {
+        unsigned long long* hb = (unsigned long long*)malloc(sizeof(unsigned long long) * 4 * (size_t)grid);
+        if (hb && hipStreamSynchronize(s) == hipSuccess &&
+            hipMemcpy(hb, stamp_buf, sizeof(unsigned long long) * 4 * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
+            double ticks = 0.0, real = 0.0;
+            unsigned long long first = ~0ull, last = 0;
+            int64_t n = 0;
+            for (int64_t g = p.border_wgs; g < grid; ++g) {
+                if (!hb[4 * g + 1] || hb[4 * g + 3] <= hb[4 * g + 1]) continue;
+                ticks += (double)(hb[4 * g + 2] - hb[4 * g + 0]), real += (double)(hb[4 * g + 3] - hb[4 * g + 1]), ++n;
+                if (hb[4 * g + 1] < first) first = hb[4 * g + 1];
+                if (hb[4 * g + 3] > last) last = hb[4 * g + 3];
+            }
+            if (n) fprintf(stderr, "modconv clock: mode %d K %d N %d %dx%d cfg %d%s: %.3f GHz in-kernel (%lld workgroups, mean %.0f cycles each, launch span %.1f us)\n",
+                           mode, k_ch, n_ch, h, w, best, use_dma ? " dma" : "", ticks / real * 0.1, (long long)n, ticks / n, (double)(last - first) * 0.01);
+        }
+        free(hb);
+    }
     if (act && p.splits > 1) {  // the activation needs the complete sum: one in-place elementwise pass
         const int rc = w2e_bias_act_fwd(y, bias, noise, noise_w, y, batch, n_ch, (int64_t)h * w, 0.2f, 1.4142135623730951f, stream);
         if (rc != 0) return rc;
