@@ -15,6 +15,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libw2e.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("W2E_HIPCC_FLAGS", "").split()  # e.g. -DW2E_STAMPS: diagnostic build with per-phase cycle stamps
 
 
 def sources():

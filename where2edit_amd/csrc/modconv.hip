@@ -66,6 +66,11 @@ enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
 // 4 phases x NPB/4 pixel blocks.  The per-phase form stages the activation patch once per phase (4 patches per 9 taps);
 // this one stages it once, which wins where the patch, not the weights, dominates staging (few channels, many pixels).
 constexpr int CONV_UPALL = 3;
+#ifdef W2E_STAMPS  // diagnostic build (W2E_HIPCC_FLAGS=-DW2E_STAMPS): 8 words per workgroup, see the W2E_TUNE_CLOCK report
+constexpr int STAMP_STRIDE = 8;
+#else
+constexpr int STAMP_STRIDE = 4;
+#endif
 __host__ __device__ constexpr bool is_up(int mode) { return mode == W2E_CONV_UP || mode == CONV_UPALL; }
 
 // Upper bound of ceil(patch / threads) for a tile of `tm` pixels (the host refuses geometries beyond it).
@@ -311,8 +316,8 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int k_lo = ks * p.k_per;
     const int k_hi = (p.tune_skip & 2) ? k_lo : ((k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K);
     if (p.stamps && tid == 0) {
-        p.stamps[4 * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-        p.stamps[4 * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+        p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
@@ -540,9 +545,21 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         }
         const int my_pos = (NT == 512) ? (swave >> 2) : 0;
         int stage = 0;
+#ifdef W2E_STAMPS
+        unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#endif
         for (int k0 = k_lo; k0 < k_hi; k0 += KC, stage ^= 1) {
+#ifdef W2E_STAMPS
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            const unsigned long long tb = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long tc = __builtin_amdgcn_s_memtime();
+            st_wait += tb - ta, st_bar += tc - tb;
+#else
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of chunk k0 have landed ...
             __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
+#endif
             const float4* wsc = reinterpret_cast<const float4*>(smem + stage * stage_floats);
             const float4* xsc = wsc + WS_FLOATS / 4;
             float4 s4[KC / 8];
@@ -550,9 +567,25 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
             for (int sub = 0; sub < KC / 8; ++sub) s4[sub] = st[((k0 >> 3) + sub) * 2 + half];
             const bool do_pf = k0 + KC < k_hi;
             mfma_chunk<MODE, NOB, NPB, KC, TN, 0, 0, true>(acc, wsc, xsc, a_base, base, p.pw, p.plane, s4, [&](int pos) __attribute__((always_inline)) {
+#ifdef W2E_STAMPS
+                if (do_pf && pos == my_pos) {
+                    const unsigned long long ti = __builtin_amdgcn_s_memtime();
+                    issue(k0 + KC, stage ^ 1);
+                    st_issue += __builtin_amdgcn_s_memtime() - ti;
+                }
+#else
                 if (do_pf && pos == my_pos) issue(k0 + KC, stage ^ 1);
+#endif
             });
         }
+#ifdef W2E_STAMPS
+        if (p.stamps && tid == 0) {
+            p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 4] = st_wait;
+            p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 5] = st_bar;
+            p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 6] = __builtin_amdgcn_s_memtime() - st_t0;
+            p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 7] = st_issue;
+        }
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -682,8 +715,8 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         if (tid < TN && n0 + tid < p.N) atomicAdd(&p.dot_out[(int64_t)b * p.N + n0 + tid], red[tid]);
     }
     if (p.stamps && tid == 0) {
-        p.stamps[4 * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-        p.stamps[4 * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -994,9 +1027,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         if (grid > stamp_cap) {
             if (stamp_buf) (void)hipFree(stamp_buf);
             stamp_cap = grid, stamp_buf = nullptr;
-            if (hipMalloc((void**)&stamp_buf, sizeof(unsigned long long) * 4 * (size_t)stamp_cap) != hipSuccess) stamp_buf = nullptr, stamp_cap = 0;
+            if (hipMalloc((void**)&stamp_buf, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)stamp_cap) != hipSuccess) stamp_buf = nullptr, stamp_cap = 0;
         }
-        if (stamp_buf && hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * 4 * (size_t)grid, s) == hipSuccess) p.stamps = stamp_buf, stamped = true;
+        if (stamp_buf && hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid, s) == hipSuccess) p.stamps = stamp_buf, stamped = true;
     }
     if (p.splits > 1 &&
         hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
@@ -1029,18 +1062,24 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
     W2E_LAUNCH_CHECK("modconv3x3");
     if (stamped) {
-        unsigned long long* hb = (unsigned long long*)malloc(sizeof(unsigned long long) * 4 * (size_t)grid);
+        unsigned long long* hb = (unsigned long long*)malloc(sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid);
         if (hb && hipStreamSynchronize(s) == hipSuccess &&
-            hipMemcpy(hb, stamp_buf, sizeof(unsigned long long) * 4 * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
+            hipMemcpy(hb, stamp_buf, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid, hipMemcpyDeviceToHost) == hipSuccess) {
             double ticks = 0.0, real = 0.0;
             unsigned long long first = ~0ull, last = 0;
             int64_t n = 0;
-            for (int64_t g = p.border_wgs; g < grid; ++g) {
-                if (!hb[4 * g + 1] || hb[4 * g + 3] <= hb[4 * g + 1]) continue;
-                ticks += (double)(hb[4 * g + 2] - hb[4 * g + 0]), real += (double)(hb[4 * g + 3] - hb[4 * g + 1]), ++n;
-                if (hb[4 * g + 1] < first) first = hb[4 * g + 1];
-                if (hb[4 * g + 3] > last) last = hb[4 * g + 3];
+            double ph[4] = {0.0, 0.0, 0.0, 0.0};  // diagnostic build: vmcnt wait, barrier wait, K loop, DMA issue (wave 0)
+            for (int64_t g0 = p.border_wgs; g0 < grid; ++g0) {
+                const unsigned long long* e = hb + STAMP_STRIDE * g0;
+                if (!e[1] || e[3] <= e[1]) continue;
+                ticks += (double)(e[2] - e[0]), real += (double)(e[3] - e[1]), ++n;
+                if (e[1] < first) first = e[1];
+                if (e[3] > last) last = e[3];
+                for (int q = 4; q < STAMP_STRIDE; ++q) ph[q - 4] += (double)e[q];
             }
+            if (n && STAMP_STRIDE == 8 && use_dma)
+                fprintf(stderr, "modconv phases (wave 0, mean cycles per workgroup): K loop %.0f, of it vmcnt(0) wait %.0f, barrier %.0f, DMA issue %.0f\n",
+                        ph[2] / n, ph[0] / n, ph[1] / n, ph[3] / n);
             if (n) fprintf(stderr, "modconv clock: mode %d K %d N %d %dx%d cfg %d%s: %.3f GHz in-kernel (%lld workgroups, mean %.0f cycles each, launch span %.1f us)\n",
                            mode, k_ch, n_ch, h, w, best, use_dma ? " dma" : "", ticks / real * 0.1, (long long)n, ticks / n, (double)(last - first) * 0.01);
         }
