@@ -966,9 +966,10 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         }
     }
     if (const char* sk = getenv("W2E_TUNE_SKIP")) p.tune_skip = atoi(sk);
-    if (const char* force = getenv("W2E_TUNE_CFG")) {  // tuning aid (tools/layer_bench.py): "<cfg>[,<splits>]"
-        int fc = -1, fs = 1;
-        if (sscanf(force, "%d,%d", &fc, &fs) >= 1 && fc >= 0 && fc < (use_all ? kNumCfgAll : ncfg)) best = fc, best_splits = fs > 0 ? fs : 1;
+    if (const char* force = getenv("W2E_TUNE_CFG")) {  // tuning aid (tools/layer_bench.py): "<cfg>[,<splits>[,<mode>]]"
+        int fc = -1, fs = 1, fm = -1;  // optional third field: only launches of that mode
+        if (sscanf(force, "%d,%d,%d", &fc, &fs, &fm) >= 1 && fc >= 0 && fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode))
+            best = fc, best_splits = fs > 0 ? fs : 1;
     }
     if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
