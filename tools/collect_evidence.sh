@@ -7,7 +7,7 @@ O=gpurun_out/ev_r1
 rm -rf $O; mkdir -p $O
 timeout -k 10 400 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
 echo bench done
-timeout -k 10 200 python3 tools/layer_bench.py > $O/layer_bench.txt 2>&1
+timeout -k 10 200 python3 tools/layer_bench.py --warm 1.5 --iters 50 > $O/layer_bench.txt 2>&1
 echo layer done
 timeout -k 10 200 python3 tools/mem_bench.py > $O/mem_bench.txt 2>&1
 echo mem done

@@ -34,7 +34,15 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", type=str, default="", help="comma list of layer indices")
+    ap.add_argument("--warm", type=float, default=0.0, help="seconds of GPU load before the first measurement (a fresh box "
+                    "starts at idle clocks: short runs of the first layers read low without it)")
     args = ap.parse_args()
+    if args.warm > 0:
+        import time
+        a = torch.randn(4096, 4096, device="cuda")
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.warm:
+            (a @ a).sum().item()
     B = args.batch
     dev = "cuda"
     tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}

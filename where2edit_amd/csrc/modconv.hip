@@ -956,6 +956,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
                 const double atomics = sp > 1 ? (double)tn * tm * 4.0 / 64.0 * 120.0 : 0.0;
                 double cost = ceil(tiles * sp / 256.0) * ((9.0 * unit + t_stage) / sp + 6000.0 + atomics);  // 4 output planes per tile
                 if (sp > 1) cost = cost * 1.06 + 8000.0;
+                if (c == 0) cost *= 1.03;  // measured: the 64x256 tile (1) beats 128x128 (0) by 2-3 % on the 64^2 / 128^2 layers
                 if (best_a < 0 || cost < best_a_cost * 0.995) best_a = c, best_a_cost = cost, best_a_splits = sp;
             }
         }
@@ -989,12 +990,12 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     const int nt_best = 64 * cfg.wo * cfg.wp;
     // LDS-DMA pipeline (two LDS stages + the in_scale table): where it is instantiated and fits
     // W2E_TUNE_DMA: 0 never, 1 wherever instantiated; default = where it measured faster (tools/layer_bench.py, batch 4):
-    // the 512-thread 8-accumulator SAME tiles (+1.5-3 %) and the all-phase UP tile 0 (+2 %); not DOWN (-1-2 %), not the
+    // the 512-thread 8-accumulator SAME tiles (+1.5-3 %) and the all-phase UP tiles 0 / 1 at K >= 256 (+2-3 %); not DOWN (-1-2 %), not the
     // 256-thread 32x512 tile of the 1024^2 layer (two LDS stages leave room for 2 instead of 3 workgroups per CU: -11 %)
     static const int tune_dma = getenv("W2E_TUNE_DMA") ? atoi(getenv("W2E_TUNE_DMA")) : -1;
     bool use_dma = false;
     size_t lds_dma = 0;
-    const bool dma_auto = use_all ? best == 0 : (mode == W2E_CONV_SAME && best <= 2);
+    const bool dma_auto = use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
     if ((tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
