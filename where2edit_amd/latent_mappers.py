@@ -1,6 +1,8 @@
 """mapper/latent_mappers.py surface (same class names, `opts` fields, state_dict keys, Q2 PixelNorm axis).
 The MLPs are [B*n,512]x[512,512] GEMMs -- rocBLAS through torch -- with the fused
 bias+LeakyReLU on the HIP op; these are the trainable parameters whose gradients are all-reduced."""
+import os
+
 import torch
 from torch import nn
 from torch.nn import Module
@@ -8,6 +10,44 @@ from torch.nn import Module
 from .stylegan2 import EqualLinear, PixelNorm
 
 STYLESPACE_DIMENSIONS = [512 for _ in range(15)] + [256, 256, 256] + [128, 128, 128] + [64, 64, 64] + [32, 32]
+
+
+class _ScaleParams(torch.autograd.Function):
+    """(w_i * w_scale ..., b_i * b_scale ...) for a list of EqualLinear layers that share scale and lr_mul: ONE multi-tensor
+    kernel per group in each direction instead of two elementwise kernels per layer per direction (model.py:151-158 does the
+    products per layer; the values are the same)."""
+
+    @staticmethod
+    def forward(ctx, w_scale, b_scale, n, *params):
+        ctx.cfg = (w_scale, b_scale, n)
+        ws = torch._foreach_mul(list(params[:n]), w_scale)
+        bs = torch._foreach_mul(list(params[n:]), b_scale)
+        return (*ws, *bs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        w_scale, b_scale, n = ctx.cfg
+        out = [None] * len(grads)
+        for lo, hi, sc in ((0, n, w_scale), (n, len(grads), b_scale)):
+            idx = [i for i in range(lo, hi) if grads[i] is not None]
+            if idx:
+                for i, g in zip(idx, torch._foreach_mul([grads[i] for i in idx], sc)):
+                    out[i] = g
+        return (None, None, None, *out)
+
+
+def scaled_parameters(mappers):
+    """{EqualLinear: (weight*scale, bias*lr_mul)} for every EqualLinear of `mappers`, or None when the layers do not share
+    one scale / lr_mul (the style-space mappers: per-layer widths) or nothing needs a gradient."""
+    if os.environ.get("W2E_TUNE_NO_PSCALE"):  # tuning aid: the per-layer products
+        return None
+    layers = [m for mp in mappers for m in mp.mapping if isinstance(m, EqualLinear)]
+    if not layers or any(m.bias is None or m.scale != layers[0].scale or m.lr_mul != layers[0].lr_mul for m in layers):
+        return None
+    if not (torch.is_grad_enabled() and any(m.weight.requires_grad for m in layers)):
+        return None  # frozen / no_grad: EqualLinear's own cached products
+    outs = _ScaleParams.apply(layers[0].scale, layers[0].lr_mul, len(layers), *[m.weight for m in layers], *[m.bias for m in layers])
+    return {m: (outs[i], outs[len(layers) + i]) for i, m in enumerate(layers)}
 
 
 class Mapper(Module):
@@ -22,8 +62,14 @@ class Mapper(Module):
             layers.append(EqualLinear(latent_dim, latent_dim, lr_mul=0.01, activation="fused_lrelu"))
         self.mapping = nn.Sequential(*layers)
 
-    def forward(self, x):
-        return self.mapping(x)
+    def forward(self, x, scaled=None):
+        if scaled is None:
+            scaled = scaled_parameters([self])
+        if scaled is None:
+            return self.mapping(x)
+        for m in self.mapping:
+            x = m(x, scaled[m]) if isinstance(m, EqualLinear) else m(x)
+        return x
 
 
 class SingleMapper(Module):
@@ -53,9 +99,12 @@ class LevelsMapper(Module):
 
     def forward(self, x):
         x_coarse, x_medium, x_fine = x[:, :4, :], x[:, 4:8, :], x[:, 8:, :]
-        x_coarse = self.course_mapping(x_coarse) if not self.opts.no_coarse_mapper else torch.zeros_like(x_coarse)
-        x_medium = self.medium_mapping(x_medium) if not self.opts.no_medium_mapper else torch.zeros_like(x_medium)
-        x_fine = self.fine_mapping(x_fine) if not self.opts.no_fine_mapper else torch.zeros_like(x_fine)
+        active = [getattr(self, n) for n, off in (("course_mapping", self.opts.no_coarse_mapper), ("medium_mapping", self.opts.no_medium_mapper),
+                                                  ("fine_mapping", self.opts.no_fine_mapper)) if not off]
+        sc = scaled_parameters(active) if active else None  # the weight*scale / bias*lr_mul products of all levels at once
+        x_coarse = self.course_mapping(x_coarse, sc) if not self.opts.no_coarse_mapper else torch.zeros_like(x_coarse)
+        x_medium = self.medium_mapping(x_medium, sc) if not self.opts.no_medium_mapper else torch.zeros_like(x_medium)
+        x_fine = self.fine_mapping(x_fine, sc) if not self.opts.no_fine_mapper else torch.zeros_like(x_fine)
         return torch.cat([x_coarse, x_medium, x_fine], dim=1)
 
 

@@ -132,8 +132,10 @@ class EqualLinear(nn.Module):
             self._scaled_key = key
         return self._scaled_val
 
-    def forward(self, input):
-        w, b = self._scaled()
+    def forward(self, input, scaled=None):
+        """`scaled` = (weight*scale, bias*lr_mul) computed by the caller (latent_mappers batches those products over all
+        of a mapper's layers); default: this layer's own."""
+        w, b = scaled if scaled is not None else self._scaled()
         if self.activation:
             return fused_leaky_relu(F.linear(input, w), b)
         return F.linear(input, w, bias=b)
