@@ -518,3 +518,44 @@ def test_modconv_abi_non_square_and_ragged_channels(b, k, n, h, w):
     xb = torch.randn(b, k, 2 * h + 1, 2 * w + 1, generator=g).to(DEV)
     y, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
     assert_close(y, F.conv2d(xb.double() * s_in.double()[:, :, None, None], wd, stride=2) * so, FWD_TOL, "down")
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("b,k,n,h,w", [(2, 20, 40, 37, 53), (1, 8, 8, 70, 33), (2, 33, 130, 16, 100)])
+def test_modconv_lds_dma_pipeline_on_ragged_shapes(cfg, b, k, n, h, w, monkeypatch):
+    """The LDS-DMA K-loop pipeline (the 512-thread tiles; picked by the cost model only for the large layers) forced onto
+    shapes with ragged channel counts, odd sizes and partial tiles: the zero padding there is entirely the buffer range
+    check of `buffer_load ... lds` (halo pixels, channels >= K, weight groups past K).  SAME plain / fused activation / dot
+    epilogue and the all-phase UP form, against float64 convolutions."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(77 * k + n + cfg)
+    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+    scale = (k * 9) ** -0.5
+    x = torch.randn(b, k, h, w, generator=g).to(DEV)
+    s_in = (torch.randn(b, k, generator=g) * 0.3 + 1).to(DEV)
+    s_out = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    wd, xd = wt.double() * scale, x.double() * s_in.double()[:, :, None, None]
+    so = s_out.double()[:, :, None, None]
+    ref = F.conv2d(xd, wd, padding=1) * so
+    fwd = K.conv_pack(wt, scale, False, False)
+    monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,0")  # SAME launches only; read by the library at every call
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
+    assert_close(y, ref, FWD_TOL, "same")
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, None, None, h, w)  # no modulation: the in_scale table is all ones
+    assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "same, unmodulated")
+    noise = torch.randn(1, 1, h, w, generator=g).to(DEV)
+    nw, bias = torch.randn(1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    pre = ref + nw.double() * noise.double() + bias.double()[None, :, None, None]
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
+    assert_close(y, F.leaky_relu(pre, 0.2) * 2 ** 0.5, FWD_TOL, "same + act")
+    dw = torch.randn(b, n, h, w, generator=g).to(DEV)
+    y, dot = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, dot_with=dw)
+    assert_close(y, ref, FWD_TOL, "same (dot epilogue) y")
+    assert_close(dot, (ref / so * dw.double()).sum((2, 3)), 5e-4, "dot_out")
+    if cfg <= 1:  # all-phase UP tiles 0 / 1 (tile 1 takes the pipeline from K >= 256 on: covered by the full-size tests)
+        monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,1")
+        wt_t = torch.randn(k, n, 3, 3, generator=g).to(DEV)
+        up = K.conv_pack(wt_t.permute(1, 0, 2, 3).contiguous(), scale, False, False)
+        t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
+        assert_close(K.unplanar(t, w), F.conv_transpose2d(xd, wt_t.double() * scale, stride=2) * so, FWD_TOL, "up")
