@@ -65,12 +65,17 @@ class Ranger(Optimizer):
                 state["step"] += 1
                 by_step.setdefault(state["step"], []).append(p)
             for step, params in by_step.items():
-                grads = []
-                for p in params:
-                    g = p.grad.float()
-                    if self.use_gc and g.dim() > self.gc_gradient_threshold:  # gradient centralisation (ranger.py:112)
-                        g = g - g.mean(dim=tuple(range(1, g.dim())), keepdim=True)
-                    grads.append(g)
+                grads = [p.grad.float() for p in params]
+                if self.use_gc:  # gradient centralisation (ranger.py:112): g -= mean over all dims but the first
+                    by_shape = {}
+                    for i, g in enumerate(grads):
+                        if g.dim() > self.gc_gradient_threshold:
+                            by_shape.setdefault(tuple(g.shape), []).append(i)
+                    for idx in by_shape.values():  # same-shaped gradients (the mapper's 12 [512,512] weights): one stacked mean
+                        st = torch.stack([grads[i] for i in idx])  # a copy: p.grad itself stays as autograd left it
+                        st.sub_(st.mean(dim=tuple(range(2, st.dim())), keepdim=True))
+                        for i, g in zip(idx, st.unbind(0)):
+                            grads[i] = g
                 exp_avg = [self.state[p]["exp_avg"] for p in params]
                 exp_avg_sq = [self.state[p]["exp_avg_sq"] for p in params]
                 torch._foreach_mul_(exp_avg_sq, beta2)
