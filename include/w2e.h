@@ -120,6 +120,11 @@ int w2e_torgb_fwd(const float* x, const float* wmod, const float* bias, const fl
 /* gx[b,i,p] = sum_c wmod[b,c,i]*gy[b,c,p];  gwmod[b,c,i] = sum_p x[b,i,p]*gy[b,c,p] (written). */
 int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx, float* gwmod, int batch, int cin,
                   int h, int w, void* stream);
+/* The same with gx = gx_acc + (that sum): x (a layer's activation, model.py:542-546) feeds both its ToRGB and the next
+ * conv; passing the gradient that came back through the conv as gx_acc folds autograd's accumulation of the two into
+ * this kernel.  gx_acc NULL = w2e_torgb_bwd. */
+int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float* gy, const float* gx_acc, float* gx, float* gwmod,
+                      int batch, int cin, int h, int w, void* stream);
 
 /* ---- K5  CLIP preprocessing  (criteria/clip_loss.py:11-12,15) ------------------------------
  * AvgPool2d(size/32)(Upsample(x7, nearest)(img)) in closed form: [planes,size,size] -> [planes,224,224];

@@ -559,3 +559,35 @@ def test_modconv_lds_dma_pipeline_on_ragged_shapes(cfg, b, k, n, h, w, monkeypat
         up = K.conv_pack(wt_t.permute(1, 0, 2, 3).contiguous(), scale, False, False)
         t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
         assert_close(K.unplanar(t, w), F.conv_transpose2d(xd, wt_t.double() * scale, stride=2) * so, FWD_TOL, "up")
+
+
+@pytest.mark.parametrize("cin,h,with_skip", [(32, 64, True), (12, 18, False), (512, 8, True)])
+def test_to_rgb_passthrough_joins_gradients(cin, h, with_skip):
+    """to_rgb(..., passthrough=True) hands x on to the next layer through the ToRGB node; the gradient that comes back
+    through that second output is folded into the ToRGB input gradient by w2e_torgb_bwd_acc.  Same values and gradients
+    as the plain form, where autograd adds the two."""
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(5 * cin + h)
+    b = 2
+    k4 = cu(seeded.fir_kernel(gain=4.0))
+    data = [torch.randn(b, cin, h, h, generator=g), torch.randn(b, 3, cin, generator=g) * 0.2, torch.randn(1, 3, 1, 1, generator=g)]
+    skip0 = torch.randn(b, 3, h // 2, h // 2, generator=g) if with_skip else None
+    r, q = torch.randn(b, 3, h, h, generator=g).to(DEV), torch.randn(b, cin, h, h, generator=g).to(DEV)
+
+    def run(passthrough):
+        x, wmod, bias = [t.to(DEV).requires_grad_(True) for t in data]
+        skip = skip0.to(DEV).requires_grad_(True) if with_skip else None
+        if passthrough:
+            y, xp = K.to_rgb(x, wmod, bias, skip, k4 if with_skip else None, True)
+            assert xp.data_ptr() == x.data_ptr()
+        else:
+            y, xp = K.to_rgb(x, wmod, bias, skip, k4 if with_skip else None), x
+        loss = (y * r).sum() + (torch.tanh(xp) * q).sum()
+        grads = torch.autograd.grad(loss, [x, wmod, bias] + ([skip] if with_skip else []))
+        return y.detach(), grads
+
+    y_a, g_a = run(True)
+    y_b, g_b = run(False)
+    assert torch.equal(y_a, y_b)
+    for a, bb, name in zip(g_a, g_b, ["gx", "gwmod", "gbias", "gskip"]):
+        assert_close(a, bb, 1e-6, name)

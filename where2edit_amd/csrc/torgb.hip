@@ -102,12 +102,13 @@ __device__ __forceinline__ float wave_sum64(float v) {
 
 // One wave per (b, channel i, pixel split): gx[b,i,p] = sum_c wmod[b,c,i]*gy[b,c,p] and
 // gwmod[b,c,i] (+)= sum_p x[b,i,p]*gy[b,c,p].  The 4 waves of a block take 4 consecutive channels of the
-// same pixel range so their gy reads share L1.
-template <int V>
+// same pixel range so their gy reads share L1.  ACC: gx = gx_acc + (that sum) -- the gradient that reached x through its
+// other consumer (the next conv) is folded in here instead of by a separate elementwise add of two activation-sized tensors.
+template <int V, bool ACC>
 __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wmod,
-                                                        const float* __restrict__ gy, float* __restrict__ gx,
-                                                        float* __restrict__ gwmod, int cin, int64_t HW, int splits,
-                                                        int64_t per_split) {
+                                                        const float* __restrict__ gy, const float* __restrict__ gx_acc,
+                                                        float* __restrict__ gx, float* __restrict__ gwmod, int cin,
+                                                        int64_t HW, int splits, int64_t per_split) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int split = blockIdx.x % splits;
     const int i = (blockIdx.x / splits) * 4 + wave;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
                 w2 = wmod[((int64_t)b * 3 + 2) * cin + i];
     const float* xp = x + ((int64_t)b * cin + i) * HW;
     float* gp = gx + ((int64_t)b * cin + i) * HW;
+    const float* ap = ACC ? gx_acc + ((int64_t)b * cin + i) * HW : nullptr;
     const float* g0 = gy + (int64_t)b * 3 * HW;
     const int64_t lo = split * per_split, hi = (lo + per_split < HW) ? lo + per_split : HW;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -132,6 +134,10 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
             r.y = w0 * a.y + w1 * bb.y + w2 * c.y;
             r.z = w0 * a.z + w1 * bb.z + w2 * c.z;
             r.w = w0 * a.w + w1 * bb.w + w2 * c.w;
+            if (ACC) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + p);
+                r.x += av.x, r.y += av.y, r.z += av.z, r.w += av.w;
+            }
             *reinterpret_cast<float4*>(gp + p) = r;
             s0 += xv.x * a.x + xv.y * a.y + xv.z * a.z + xv.w * a.w;
             s1 += xv.x * bb.x + xv.y * bb.y + xv.z * bb.z + xv.w * bb.w;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
     } else {
         for (int64_t p = lo + lane; p < hi; p += 64) {
             const float xv = xp[p], a = g0[p], bb = g0[HW + p], c = g0[2 * HW + p];
-            gp[p] = w0 * a + w1 * bb + w2 * c;
+            gp[p] = w0 * a + w1 * bb + w2 * c + (ACC ? ap[p] : 0.f);
             s0 += xv * a, s1 += xv * bb, s2 += xv * c;
         }
     }
@@ -190,6 +196,11 @@ extern "C" int w2e_torgb_fwd(const float* x, const float* wmod, const float* bia
 
 extern "C" int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx, float* gwmod, int batch,
                              int cin, int h, int w, void* stream) {
+    return w2e_torgb_bwd_acc(x, wmod, gy, nullptr, gx, gwmod, batch, cin, h, w, stream);
+}
+
+extern "C" int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float* gy, const float* gx_acc, float* gx,
+                                 float* gwmod, int batch, int cin, int h, int w, void* stream) {
     W2E_REQUIRE(x && wmod && gy && gx && gwmod, "torgb_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && cin > 0 && h > 0 && w > 0, "torgb_bwd: bad dims");
     W2E_REQUIRE(batch < 65536, "torgb_bwd: batch too large");
@@ -211,8 +222,13 @@ extern "C" int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy,
         return 2;
     }
     dim3 grid((unsigned)(ceil_div(cin, 4) * splits), (unsigned)batch);
-    if ((hw & 3) == 0) torgb_bwd_kernel<4><<<grid, 256, 0, s>>>(x, wmod, gy, gx, gwmod, cin, hw, splits, per_split);
-    else torgb_bwd_kernel<1><<<grid, 256, 0, s>>>(x, wmod, gy, gx, gwmod, cin, hw, splits, per_split);
+    if ((hw & 3) == 0) {
+        if (gx_acc) torgb_bwd_kernel<4, true><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        else torgb_bwd_kernel<4, false><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+    } else {
+        if (gx_acc) torgb_bwd_kernel<1, true><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        else torgb_bwd_kernel<1, false><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+    }
     W2E_LAUNCH_CHECK("torgb_bwd");
     return 0;
 }

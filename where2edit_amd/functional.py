@@ -291,8 +291,13 @@ def style_affine_all(latent, pack):
 
 # ------------------------------------------------------------------------------------------ K1r
 class _ToRGB(torch.autograd.Function):
+    """`passthrough`: also return x itself as a second output for the NEXT layer to consume.  x then has this node as its
+    only consumer, and the gradient coming back through the next layer arrives here as `gx_next` and is folded into the
+    ToRGB input gradient by the kernel (w2e_torgb_bwd_acc) -- instead of autograd adding two activation-sized tensors."""
+
     @staticmethod
-    def forward(ctx, x, wmod, bias, skip, upk):
+    def forward(ctx, x, wmod, bias, skip, upk, passthrough=False):
+        x_in = x
         x, wmod = _c(x), _c(wmod)
         b, cin, h, w = x.shape
         y = torch.empty((b, 3, h, w), device=x.device, dtype=torch.float32)
@@ -302,28 +307,33 @@ class _ToRGB(torch.autograd.Function):
              ptr(y), b, cin, h, w, stream_ptr())
         ctx.save_for_backward(x, wmod, upk if skip is not None else None)
         ctx.has = (bias is not None, skip is not None, tuple(bias.shape) if bias is not None else None)
+        if passthrough:
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, gx_next=None):
         x, wmod, upk = ctx.saved_tensors
         has_bias, has_skip, bias_shape = ctx.has
-        gy = _c(gy)
         b, cin, h, w = x.shape
+        if gy is None:  # only the pass-through output was used
+            return gx_next, None, None, None, None, None
+        gy = _c(gy)
         gx = torch.empty_like(x)
         gw = torch.empty_like(wmod)
-        call("w2e_torgb_bwd", ptr(x), ptr(wmod), ptr(gy), ptr(gx), ptr(gw), b, cin, h, w, stream_ptr())
+        acc = _c(gx_next) if gx_next is not None else None
+        call("w2e_torgb_bwd_acc", ptr(x), ptr(wmod), ptr(gy), ptr(acc), ptr(gx), ptr(gw), b, cin, h, w, stream_ptr())
         gb = gy.sum((0, 2, 3)).reshape(bias_shape) if (has_bias and ctx.needs_input_grad[2]) else None
         gskip = None
         if has_skip:  # adjoint of Upsample(up=2, pad=(2,1)): down=2, un-flipped taps, leading pad 4-1-2
             gskip = _upfirdn2d_raw(gy, upk, h // 2, w // 2, 1, 2, 1, 1, False)
-        return gx, gw, gb, gskip, None
+        return gx, gw, gb, gskip, None, None
 
 
-def to_rgb(x, wmod, bias, skip, upk):
-    """y = sum_i wmod[b,c,i] x[b,i] + bias + Upsample(skip)   (model.py:353-362)."""
-    return _ToRGB.apply(x, wmod, bias, skip, upk)
+def to_rgb(x, wmod, bias, skip, upk, passthrough=False):
+    """y = sum_i wmod[b,c,i] x[b,i] + bias + Upsample(skip)   (model.py:353-362); with `passthrough` -> (y, x)."""
+    return _ToRGB.apply(x, wmod, bias, skip, upk, passthrough)
 
 
 # ------------------------------------------------------------------------------------------ K5

@@ -12,6 +12,7 @@ rosinality `g_ema` checkpoints.  The arithmetic is different by design:
   * ToRGB is ONE kernel for the 1x1 modconv + bias + FIR-upsampled skip.
 """
 import math
+import os
 import random
 
 import torch
@@ -290,6 +291,9 @@ class StyledConv(nn.Module):
         return out, style
 
 
+_NO_RGBPASS = bool(os.environ.get("W2E_TUNE_NO_RGBPASS"))  # tuning aid: autograd's own accumulation instead
+
+
 class ToRGB(nn.Module):
     """model.py:343-362"""
 
@@ -300,7 +304,8 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None, input_is_stylespace=False):
+    def forward(self, input, style, skip=None, input_is_stylespace=False, passthrough=False):
+        """`passthrough` (synthesis loop, training): returns (rgb, style, input) -- see functional._ToRGB."""
         conv = self.conv
         batch = input.shape[0]
         style = conv._style(style, batch, input_is_stylespace)
@@ -317,9 +322,15 @@ class ToRGB(nn.Module):
             wsc = self._wsc
         wmod = wsc * style.reshape(batch, 1, conv.in_channel)
         fuse_skip = skip is not None and self.upsample.kernel.shape == (4, 4) and self.upsample.factor == 2
-        out = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None)
+        passed = None
+        if passthrough:
+            out, passed = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None, True)
+        else:
+            out = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None)
         if skip is not None and not fuse_skip:
             out = out + self.upsample(skip)
+        if passthrough:
+            return out, style, passed
         return out, style
 
 
@@ -454,7 +465,12 @@ class Generator(nn.Module):
         for n, (mod, is_rgb, widx, nidx) in enumerate(plan):
             sty = latent[n] if input_is_stylespace else latent[:, widx]
             if is_rgb:
-                skip, s = mod(out, sty, skip, input_is_stylespace=input_is_stylespace)
+                # the activation feeds this ToRGB and the next conv: route it THROUGH the ToRGB node when gradients flow
+                # (one consumer, the two gradients are joined inside torgb_bwd instead of by an elementwise add)
+                if on_layer is None and n + 1 < len(plan) and torch.is_grad_enabled() and out.requires_grad and not _NO_RGBPASS:
+                    skip, s, out = mod(out, sty, skip, input_is_stylespace=input_is_stylespace, passthrough=True)
+                else:
+                    skip, s = mod(out, sty, skip, input_is_stylespace=input_is_stylespace)
                 if on_layer is not None:
                     skip = on_layer(n, True, skip)
             else:
