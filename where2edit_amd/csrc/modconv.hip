@@ -1000,7 +1000,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
         const int slots = (int)ceil_div(4 * plane16, nt_best);
-        if (lds_dma <= 150 * 1024 && slots <= 4 * max_patch_slots(up ? W2E_CONV_UP : mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
+        // (the pipeline addresses channels up to K+7 of an image with 32-bit byte offsets: they must not wrap)
+        const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
+        if (off_ok && lds_dma <= 150 * 1024 && slots <= 4 * max_patch_slots(up ? W2E_CONV_UP : mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
         if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "  lds-dma pipeline: %s (%zu B LDS, %d slots)\n", use_dma ? "yes" : "no", lds_dma, slots);
     }
     const int kdeep_best = (up && !use_all && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
