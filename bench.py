@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 G_FWD_GFLOP_1024 = 148.13  # 3x3 modconv stack per image forward (ToRGB's 0.39 is not MFMA work)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md); only quoted with --conv-precision bf16x3
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -140,10 +141,16 @@ def main():
     ap.add_argument("--spinup", type=float, default=0.7,
                     help="seconds of untimed G(w) forwards before the W warm-up steps: brings a fresh box's GPU out of its "
                          "idle clocks even when the caller asks for only a few warm-up steps (reported in config)")
+    ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"],
+                    help="f32 (default): exact fp32 MFMA everywhere.  bf16x3: the SAME-resolution conv tiles compute each fp32 "
+                         "product as three bf16 products (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product; every "
+                         "parity test passes with it) -- opt-in, reported as dtype bf16x3")
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3],
                     help="BASELINE configs index + 1: 2 = clip_loss mapper step (the headline, default); 3 = the same step with "
                          "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8)")
     args = ap.parse_args()
+    if args.conv_precision != "f32":
+        os.environ["W2E_CONV_PRECISION"] = args.conv_precision  # read by libw2e.so at every conv launch
 
     from where2edit_amd import dist as wd
     from where2edit_amd import profiling
@@ -199,13 +206,13 @@ def main():
         "metric": "1024^2 edited images/sec per mapper step" if args.size == 1024 else f"{args.size}^2 edited images/sec per mapper step",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.conv_precision, "data": "synthetic",
         "config": {"workload": (f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
                                 f"LevelsMapper, Ranger, id_lambda=0") if args.workload == 2 else
                                (f"FFHQ-{args.size} mapper step with the region-attention mask blend at layer 13 (attention_model.py) "
                                 f"+ clip_loss + id_loss (IR-SE50, stock ops), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
-                   "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "final_loss": loss,
+                   "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
                    "spinup_s": args.spinup},
     }
     if timer is not None:
@@ -218,6 +225,11 @@ def main():
                                "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                                "launches": calls, "avg_launch_ms": ms / calls, "flop_per_launch": flops / calls,
                                "share_of_step": ms / (1e3 * dt)}
+            if args.conv_precision == "bf16x3":  # opt-in: algorithmic (fp32-conv) FLOPs against the bf16 matrix peak
+                out["roofline"].update({
+                    "kernel": "w2e::modconv_kernel (SAME tiles: fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16, 3.33 issued "
+                              "bf16 FLOPs per algorithmic FLOP; up/down-sampling tiles: fp32 MFMA 32x32x2)",
+                    "peak": BF16_MFMA_PEAK_TFLOPS, "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None})
         c2, ms2, by2 = s.get("upfirdn2d", (0, 0.0, 0.0))
         if c2:
             out["roofline_hbm"] = {"bound": "hbm", "kernel": "w2e::upfirdn_*", "achieved": by2 / (ms2 * 1e-3) / 1e9,

@@ -591,3 +591,55 @@ def test_to_rgb_passthrough_joins_gradients(cin, h, with_skip):
     assert torch.equal(y_a, y_b)
     for a, bb, name in zip(g_a, g_b, ["gx", "gwmod", "gbias", "gskip"]):
         assert_close(a, bb, 1e-6, name)
+
+
+@pytest.mark.parametrize("b,k,n,h,w,cfg", [(2, 20, 40, 37, 53, 0), (1, 8, 8, 70, 33, 1), (2, 33, 130, 16, 100, 2), (1, 24, 32, 40, 64, 8),
+                                            (1, 256, 256, 64, 64, 0)])
+def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, monkeypatch):
+    """Opt-in W2E_CONV_PRECISION=bf16x3: the SAME-mode tiles of the DMA pipeline compute each fp32 product as three bf16
+    products (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, two taps per MFMA).  Same bar as the exact path:
+    FWD_TOL = 1e-4 relative against float64 convolutions (north_star: 1e-3), plain / fused activation / dot epilogue,
+    ragged channel counts and partial tiles included."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(31 * k + n + cfg)
+    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+    scale = (k * 9) ** -0.5
+    x = torch.randn(b, k, h, w, generator=g).to(DEV)
+    s_in = (torch.randn(b, k, generator=g) * 0.3 + 1).to(DEV)
+    s_out = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    wd, xd = wt.double() * scale, x.double() * s_in.double()[:, :, None, None]
+    so = s_out.double()[:, :, None, None]
+    ref = F.conv2d(xd, wd, padding=1) * so
+    fwd = K.conv_pack(wt, scale, False, False)
+    y_exact, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
+    monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,0")
+    monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
+    assert_close(y, ref, FWD_TOL, "same")
+    assert not torch.equal(y, y_exact), "the split path did not run"
+    noise = torch.randn(1, 1, h, w, generator=g).to(DEV)
+    nw, bias = torch.randn(1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    pre = ref + nw.double() * noise.double() + bias.double()[None, :, None, None]
+    y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
+    assert_close(y, F.leaky_relu(pre, 0.2) * 2 ** 0.5, FWD_TOL, "same + act")
+    dw = torch.randn(b, n, h, w, generator=g).to(DEV)
+    y, dot = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, dot_with=dw)
+    assert_close(y, ref, FWD_TOL, "same (dot epilogue) y")
+    assert_close(dot, (ref / so * dw.double()).sum((2, 3)), 5e-4, "dot_out")
+
+
+def test_generator1024_golden_with_bf16x3(monkeypatch):
+    """The FFHQ-1024 generator against the values captured from the reference with the opt-in bf16x3 conv tiles: the
+    north_star tolerance (1e-3 relative) holds through the 17 stacked layers."""
+    from where2edit_amd.attention_model import Generator as AttGenerator
+    monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+    size = 1024
+    g = golden("generator_big")
+    gen = _gen(size, AttGenerator)
+    w = cu(seeded.wplus_latents(1, gen.n_latent, salt=size))
+    with torch.no_grad():
+        img, _, svec, feats = gen([w], input_is_latent=True, randomize_noise=False, return_features=True)
+    st = size // 32
+    assert_close(img[:, :, ::st, ::st], g[f"g{size}.image_strided"], 1e-3, "image (north_star tolerance)")
+    assert abs(img.double().abs().sum().item() / float(g[f"g{size}.image_abs_sum"]) - 1) < 1e-4

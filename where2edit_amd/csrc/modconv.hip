@@ -25,6 +25,7 @@
 // conv = adjoint of UP).
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -282,7 +283,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
     }
 }
 
-template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, bool DMA>
+template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, int DMA>
 __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
     constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
     constexpr int TN = 32 * NOB * WO;
@@ -489,7 +490,9 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         const int plane4 = p.plane * 4;
         const int stage_floats = WS_FLOATS + (KC / 8) * 2 * plane4;
         lds_char* const l0 = (lds_char*)smem;
-        float* const stw = smem + 2 * stage_floats;  // in_scale table [ceil(K/8)][2] float4: (g, h).c = channel 8g + 2c + h
+        // in_scale table [ceil(K/8)][2] float4: (g, h).c = channel 8g + 2c + h; after the two stages (DMA == 2: after the fp32
+        // staging area and the bf16 operand images)
+        float* const stw = smem + (DMA == 2 ? stage_floats + 4 * (20 * TN + 2 * p.plane) : 2 * stage_floats);
         const float4* const st = reinterpret_cast<const float4*>(stw);
         const int a_base = half * TN + wo * NOB * 32 + j;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -544,6 +547,80 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
             stw[e] = ch < p.K ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + ch] : 1.f) : 0.f;
         }
         const int my_pos = (NT == 512) ? (swave >> 2) : 0;
+        if constexpr (DMA == 2) {
+            // ---- opt-in (W2E_CONV_PRECISION=bf16x3): fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16.  The chunk lands by
+            // LDS-DMA in the fp32 layout (staging area S), is split into hi = bf16(a), lo = bf16(a - hi) while it is copied
+            // to the operand images -- weights BW[q][tap][TN], patch BX[q][pixel], 16 B = the chunk's 8 channels in the order
+            // 0,2,4,6,1,3,5,7, in_scale applied to the patch on the way -- and an MFMA's K = 16 is those 8 channels at TWO taps:
+            // lane-half h supplies tap 2*pair + h (tap 9 is a zero weight).  acc += hi*hi + hi*lo + lo*hi: 15 MFMAs of 32
+            // cycles per accumulator per chunk instead of 36 of 64.
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            bf16x8* const bw = reinterpret_cast<bf16x8*>(smem + stage_floats);
+            bf16x8* const bx = bw + 20 * TN;
+            const float4* const wsf = reinterpret_cast<const float4*>(smem);
+            const float4* const xsf = wsf + WS_FLOATS / 4;
+            for (int i = tid; i < 2 * TN; i += NT) {  // tap 9 of both halves: zero weights, written once
+                bf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+                bw[(i / TN) * 10 * TN + 9 * TN + (i % TN)] = z;
+            }
+            auto split8 = [](const float (&v)[8], bf16x8& hi, bf16x8& lo) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const __bf16 h = (__bf16)v[e];
+                    hi[e] = h;
+                    lo[e] = (__bf16)(v[e] - (float)h);
+                }
+            };
+            int pix[NPB];
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) pix[pb] = base[pb] - half * p.plane;
+            const int a0 = half * TN + wo * NOB * 32 + j;
+            for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();  // the chunk has landed in S; everybody is done with the previous chunk's operand images
+                for (int idx = tid; idx < 9 * TN; idx += NT) {
+                    const int tap = idx / TN, o = idx - tap * TN;
+                    const float4 f0 = wsf[(tap * 2 + 0) * TN + o], f1 = wsf[(tap * 2 + 1) * TN + o];
+                    const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                    bf16x8 hi, lo;
+                    split8(v, hi, lo);
+                    bw[idx] = hi, bw[10 * TN + idx] = lo;
+                }
+                const float4 s0 = st[(k0 >> 3) * 2], s1 = st[(k0 >> 3) * 2 + 1];
+                for (int idx = tid; idx < p.plane; idx += NT) {
+                    const float4 f0 = xsf[idx], f1 = xsf[p.plane + idx];
+                    const float v[8] = {f0.x * s0.x, f0.y * s0.y, f0.z * s0.z, f0.w * s0.w, f1.x * s1.x, f1.y * s1.y, f1.z * s1.z, f1.w * s1.w};
+                    bf16x8 hi, lo;
+                    split8(v, hi, lo);
+                    bx[idx] = hi, bx[p.plane + idx] = lo;
+                }
+                __syncthreads();  // operand images complete; S is free for the next chunk's DMA
+                const bool do_pf = k0 + KC < k_hi;
+#pragma unroll
+                for (int pair = 0; pair < 5; ++pair) {
+                    const int t0 = 2 * pair, t1 = (2 * pair + 1 < 9) ? 2 * pair + 1 : 8;
+                    const int off0 = (t0 / 3) * p.pw + t0 % 3, off1 = (t1 / 3) * p.pw + t1 % 3;
+                    const int hoff = half ? off1 : off0;
+                    bf16x8 ah[NOB], al[NOB], bh[NPB], bl[NPB];
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) ah[ob] = bw[pair * 2 * TN + a0 + ob * 32], al[ob] = bw[10 * TN + pair * 2 * TN + a0 + ob * 32];
+#pragma unroll
+                    for (int pb = 0; pb < NPB; ++pb) bh[pb] = bx[pix[pb] + hoff], bl[pb] = bx[p.plane + pix[pb] + hoff];
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                        for (int pb = 0; pb < NPB; ++pb) {
+                            acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ob], bh[pb], acc[ob][pb], 0, 0, 0);
+                            acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ob], bl[pb], acc[ob][pb], 0, 0, 0);
+                            acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ob], bh[pb], acc[ob][pb], 0, 0, 0);
+                        }
+                    if (do_pf && ((pair == 0 && my_pos == 0) || (pair == 2 && my_pos == 1))) issue(k0 + KC, 0);
+                }
+            }
+            return;
+        }
         int stage = 0;
 #ifdef W2E_STAMPS
         unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_t0 = __builtin_amdgcn_s_memtime();
@@ -746,7 +823,7 @@ struct TileCfg {
     int nob, npb, wo, wp;
 };
 
-template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, bool DMA = false>
+template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, int DMA = 0>
 static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {  // dynamic LDS above 64 KB is opt-in per kernel (gfx950: 160 KB per CU)
         static size_t allowed = 0;
@@ -764,25 +841,37 @@ static bool dma_has_cfg(bool all_phase, int cfg) {
                      : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10);
 }
 
+// opt-in bf16x3 form (W2E_CONV_PRECISION=bf16x3): the SAME-mode tiles of the DMA pipeline
+template <int EPI>
+static bool launch_x3(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    switch (cfg) {
+        case 0: launch_cfg<W2E_CONV_SAME, EPI, 2, 4, 2, 4, 8, 2>(p, grid, lds, s); return true;
+        case 1: launch_cfg<W2E_CONV_SAME, EPI, 2, 4, 1, 8, 8, 2>(p, grid, lds, s); return true;
+        case 2: launch_cfg<W2E_CONV_SAME, EPI, 1, 4, 1, 8, 8, 2>(p, grid, lds, s); return true;
+        case 8: launch_cfg<W2E_CONV_SAME, EPI, 1, 4, 1, 4, 8, 2>(p, grid, lds, s); return true;
+    }
+    return false;
+}
+
 template <int MODE, int EPI, int KC>
 static bool launch_mode_dma(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
     if constexpr (MODE == CONV_UPALL) {
         switch (cfg) {
-            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC, true>(p, grid, lds, s); return true;
-            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
-            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
-            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, true>(p, grid, lds, s); return true;
-            case 11: launch_cfg<MODE, EPI, 1, 8, 1, 8, KC, true>(p, grid, lds, s); return true;
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC, 1>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC, 1>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC, 1>(p, grid, lds, s); return true;
+            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
+            case 11: launch_cfg<MODE, EPI, 1, 8, 1, 8, KC, 1>(p, grid, lds, s); return true;
         }
         return false;
     } else {
         switch (cfg) {
-            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC, true>(p, grid, lds, s); return true;
-            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
-            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC, true>(p, grid, lds, s); return true;
-            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, true>(p, grid, lds, s); return true;
-            case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC, true>(p, grid, lds, s); return true;
-            case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC, true>(p, grid, lds, s); return true;
+            case 0: launch_cfg<MODE, EPI, 2, 4, 2, 4, KC, 1>(p, grid, lds, s); return true;
+            case 1: launch_cfg<MODE, EPI, 2, 4, 1, 8, KC, 1>(p, grid, lds, s); return true;
+            case 2: launch_cfg<MODE, EPI, 1, 4, 1, 8, KC, 1>(p, grid, lds, s); return true;
+            case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
+            case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC, 1>(p, grid, lds, s); return true;
+            case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC, 1>(p, grid, lds, s); return true;
         }
         return false;
     }
@@ -1009,6 +1098,23 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     size_t lds = (up && !use_all) ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
                                   : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
+    // W2E_CONV_PRECISION=bf16x3 (read at every call; opt-in, default = exact fp32 MFMA): the SAME-mode tiles of the DMA
+    // pipeline compute each fp32 product as three bf16 products (see DMA == 2 in the kernel)
+    const char* prec_env = getenv("W2E_CONV_PRECISION");
+    const int tune_x3 = (prec_env && strcmp(prec_env, "bf16x3") == 0) ? 1 : 0;
+    bool use_x3 = false;
+    if (tune_x3 == 1 && !use_dma && mode == W2E_CONV_SAME && best == 8 && dma_has_cfg(false, best)) {  // the 32x512 tile: not a DMA tile by default
+        const int plane16 = (p.plane + 15) & ~15;
+        const int slots = (int)ceil_div(4 * plane16, nt_best);
+        const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
+        if (off_ok && slots <= 4 * max_patch_slots(mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
+    }
+    if (tune_x3 == 1 && use_dma && mode == W2E_CONV_SAME && (best <= 2 || best == 8)) {
+        // fp32 staging area + bf16 operand images (20*tn + 2*plane 16-byte entries) + the in_scale table
+        lds_dma = sizeof(float) * (((size_t)kc * 9 * tn + (size_t)kc * p.plane) + 4 * ((size_t)20 * tn + 2 * (size_t)p.plane) + (size_t)((k_ch + 7) / 8) * 8);
+        use_x3 = lds_dma <= 150 * 1024;
+        if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "  bf16x3: %s (%zu B LDS)\n", use_x3 ? "yes" : "no", lds_dma);
+    }
     if (use_dma) lds = lds_dma;
     W2E_REQUIRE(lds <= 150 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
     const int k_gran = use_all ? kc : kc_max;
@@ -1041,7 +1147,11 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         return 2;
     }
     bool ok = false;
-    if (use_dma) {
+    if (use_x3) {
+        if (act && p.splits == 1) ok = launch_x3<EPI_ACT>(best, p, (int)grid, lds, s);
+        else if (dot_with) ok = launch_x3<EPI_DOT>(best, p, (int)grid, lds, s);
+        else ok = launch_x3<EPI_PLAIN>(best, p, (int)grid, lds, s);
+    } else if (use_dma) {
         if (mode == W2E_CONV_SAME) {
             if (act && p.splits == 1) ok = launch_mode_dma<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
             else if (dot_with) ok = launch_mode_dma<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
