@@ -142,7 +142,7 @@ def main():
                     help="seconds of untimed G(w) forwards before the W warm-up steps: brings a fresh box's GPU out of its "
                          "idle clocks even when the caller asks for only a few warm-up steps (reported in config)")
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"],
-                    help="f32 (default): exact fp32 MFMA everywhere.  bf16x3: the SAME-resolution conv tiles compute each fp32 "
+                    help="f32 (default): exact fp32 MFMA everywhere.  bf16x3: the SAME-resolution and up-sampling conv tiles compute each fp32 "
                          "product as three bf16 products (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product; every "
                          "parity test passes with it) -- opt-in, reported as dtype bf16x3")
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3],
@@ -227,8 +227,8 @@ def main():
                                "share_of_step": ms / (1e3 * dt)}
             if args.conv_precision == "bf16x3":  # opt-in: algorithmic (fp32-conv) FLOPs against the bf16 matrix peak
                 out["roofline"].update({
-                    "kernel": "w2e::modconv_kernel (SAME tiles: fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16, 3.33 issued "
-                              "bf16 FLOPs per algorithmic FLOP; up/down-sampling tiles: fp32 MFMA 32x32x2)",
+                    "kernel": "w2e::modconv_kernel (SAME and all-phase UP tiles: fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16, "
+                              "3.33 issued bf16 FLOPs per algorithmic FLOP; DOWN and low-resolution tiles: fp32 MFMA 32x32x2)",
                     "peak": BF16_MFMA_PEAK_TFLOPS, "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None})
         c2, ms2, by2 = s.get("upfirdn2d", (0, 0.0, 0.0))
         if c2:

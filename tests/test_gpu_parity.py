@@ -627,6 +627,17 @@ def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, monkeypatch):
     y, dot = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, dot_with=dw)
     assert_close(y, ref, FWD_TOL, "same (dot epilogue) y")
     assert_close(dot, (ref / so * dw.double()).sum((2, 3)), 5e-4, "dot_out")
+    if cfg <= 2 and h * w >= 256:  # the all-phase UP tiles (two taps of the same output phase per MFMA)
+        monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,1")
+        wt_t = torch.randn(k, n, 3, 3, generator=g).to(DEV)
+        up = K.conv_pack(wt_t.permute(1, 0, 2, 3).contiguous(), scale, False, False)
+        ref_t = F.conv_transpose2d(xd, wt_t.double() * scale, stride=2) * so
+        monkeypatch.delenv("W2E_CONV_PRECISION")
+        t_exact, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
+        monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+        t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
+        assert_close(K.unplanar(t, w), ref_t, FWD_TOL, "up")
+        assert not torch.equal(t, t_exact), "the split path did not run (up)"
 
 
 def test_generator1024_golden_with_bf16x3(monkeypatch):

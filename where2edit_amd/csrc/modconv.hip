@@ -573,9 +573,16 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                     lo[e] = (__bf16)(v[e] - (float)h);
                 }
             };
-            int pix[NPB];
+            // tap pairs.  SAME / DOWN: (2p, 2p+1), all into the same accumulators.  All-phase UP: the two taps of a pair must
+            // belong to the same output phase: {0,2} {6,8} -> phase 0, {1,7} -> 1, {3,5} -> 2, {4,-} -> 3
+            constexpr bool UPA = MODE == CONV_UPALL;
+            constexpr int kTap0[5] = {0, UPA ? 6 : 2, UPA ? 1 : 4, UPA ? 3 : 6, UPA ? 4 : 8};
+            constexpr int kTap1[5] = {UPA ? 2 : 1, UPA ? 8 : 3, UPA ? 7 : 5, UPA ? 5 : 7, UPA ? 4 : 8};  // (pair 4: the zero weight)
+            constexpr int kPhase[5] = {0, 0, UPA ? 1 : 0, UPA ? 2 : 0, UPA ? 3 : 0};
+            constexpr int kSlot[9] = {0, UPA ? 4 : 1, UPA ? 1 : 2, UPA ? 6 : 3, UPA ? 8 : 4, UPA ? 7 : 5, UPA ? 2 : 6, UPA ? 5 : 7, UPA ? 3 : 8};
+            int pix[NPX];
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) pix[pb] = base[pb] - half * p.plane;
+            for (int pb = 0; pb < NPX; ++pb) pix[pb] = base[pb] - half * p.plane;
             const int a0 = half * TN + wo * NOB * 32 + j;
             for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                     const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
                     bf16x8 hi, lo;
                     split8(v, hi, lo);
-                    bw[idx] = hi, bw[10 * TN + idx] = lo;
+                    bw[kSlot[tap] * TN + o] = hi, bw[10 * TN + kSlot[tap] * TN + o] = lo;
                 }
                 const float4 s0 = st[(k0 >> 3) * 2], s1 = st[(k0 >> 3) * 2 + 1];
                 for (int idx = tid; idx < p.plane; idx += NT) {
@@ -600,21 +607,24 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                 const bool do_pf = k0 + KC < k_hi;
 #pragma unroll
                 for (int pair = 0; pair < 5; ++pair) {
-                    const int t0 = 2 * pair, t1 = (2 * pair + 1 < 9) ? 2 * pair + 1 : 8;
-                    const int off0 = (t0 / 3) * p.pw + t0 % 3, off1 = (t1 / 3) * p.pw + t1 % 3;
+                    const int t0 = kTap0[pair], t1 = kTap1[pair];
+                    // patch offset of a tap relative to the lane's pixel (as in mfma_chunk)
+                    const int off0 = UPA ? -((t0 / 3) >> 1) * p.pw - ((t0 % 3) >> 1) : (t0 / 3) * p.pw + t0 % 3;
+                    const int off1 = UPA ? -((t1 / 3) >> 1) * p.pw - ((t1 % 3) >> 1) : (t1 / 3) * p.pw + t1 % 3;
                     const int hoff = half ? off1 : off0;
-                    bf16x8 ah[NOB], al[NOB], bh[NPB], bl[NPB];
+                    bf16x8 ah[NOB], al[NOB], bh[NPX], bl[NPX];
 #pragma unroll
                     for (int ob = 0; ob < NOB; ++ob) ah[ob] = bw[pair * 2 * TN + a0 + ob * 32], al[ob] = bw[10 * TN + pair * 2 * TN + a0 + ob * 32];
 #pragma unroll
-                    for (int pb = 0; pb < NPB; ++pb) bh[pb] = bx[pix[pb] + hoff], bl[pb] = bx[p.plane + pix[pb] + hoff];
+                    for (int pb = 0; pb < NPX; ++pb) bh[pb] = bx[pix[pb] + hoff], bl[pb] = bx[p.plane + pix[pb] + hoff];
 #pragma unroll
                     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                        for (int pb = 0; pb < NPB; ++pb) {
-                            acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ob], bh[pb], acc[ob][pb], 0, 0, 0);
-                            acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ob], bl[pb], acc[ob][pb], 0, 0, 0);
-                            acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ob], bh[pb], acc[ob][pb], 0, 0, 0);
+                        for (int pb = 0; pb < NPX; ++pb) {
+                            f32x16& a = acc[ob][kPhase[pair] * NPX + pb];
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ob], bh[pb], a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ob], bl[pb], a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ob], bh[pb], a, 0, 0, 0);
                         }
                     if (do_pf && ((pair == 0 && my_pos == 0) || (pair == 2 && my_pos == 1))) issue(k0 + KC, 0);
                 }
@@ -839,6 +849,17 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
 static bool dma_has_cfg(bool all_phase, int cfg) {
     return all_phase ? (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 11)
                      : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10);
+}
+
+// opt-in bf16x3 form: the all-phase UP tiles
+static bool launch_x3_up(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    switch (cfg) {
+        case 0: launch_cfg<CONV_UPALL, EPI_PLAIN, 2, 4, 2, 4, 8, 2>(p, grid, lds, s); return true;
+        case 1: launch_cfg<CONV_UPALL, EPI_PLAIN, 2, 4, 1, 8, 8, 2>(p, grid, lds, s); return true;
+        case 2: launch_cfg<CONV_UPALL, EPI_PLAIN, 1, 4, 1, 8, 8, 2>(p, grid, lds, s); return true;
+        case 11: launch_cfg<CONV_UPALL, EPI_PLAIN, 1, 8, 1, 8, 8, 2>(p, grid, lds, s); return true;
+    }
+    return false;
 }
 
 // opt-in bf16x3 form (W2E_CONV_PRECISION=bf16x3): the SAME-mode tiles of the DMA pipeline
@@ -1109,7 +1130,13 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
         if (off_ok && slots <= 4 * max_patch_slots(mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
     }
-    if (tune_x3 == 1 && use_dma && mode == W2E_CONV_SAME && (best <= 2 || best == 8)) {
+    if (tune_x3 == 1 && !use_dma && use_all && (best <= 2 || best == 11)) {  // all-phase UP tiles that are not DMA tiles by default
+        const int plane16 = (p.plane + 15) & ~15;
+        const int slots = (int)ceil_div(4 * plane16, nt_best);
+        const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
+        if (off_ok && slots <= 4 * max_patch_slots(W2E_CONV_UP, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
+    }
+    if (tune_x3 == 1 && use_dma && ((mode == W2E_CONV_SAME && (best <= 2 || best == 8)) || (use_all && (best <= 2 || best == 11)))) {
         // fp32 staging area + bf16 operand images (20*tn + 2*plane 16-byte entries) + the in_scale table
         lds_dma = sizeof(float) * (((size_t)kc * 9 * tn + (size_t)kc * p.plane) + 4 * ((size_t)20 * tn + 2 * (size_t)p.plane) + (size_t)((k_ch + 7) / 8) * 8);
         use_x3 = lds_dma <= 150 * 1024;
@@ -1147,7 +1174,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         return 2;
     }
     bool ok = false;
-    if (use_x3) {
+    if (use_x3 && use_all) {
+        ok = launch_x3_up(best, p, (int)grid, lds, s);
+    } else if (use_x3) {
         if (act && p.splits == 1) ok = launch_x3<EPI_ACT>(best, p, (int)grid, lds, s);
         else if (dot_with) ok = launch_x3<EPI_DOT>(best, p, (int)grid, lds, s);
         else ok = launch_x3<EPI_PLAIN>(best, p, (int)grid, lds, s);
