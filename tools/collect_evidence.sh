@@ -7,6 +7,9 @@ O=gpurun_out/ev_r1
 rm -rf $O; mkdir -p $O
 timeout -k 10 400 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
 echo bench done
+timeout -k 10 300 python3 bench.py --conv-precision bf16x3 --no-cpu-baseline > $O/bench_line_bf16x3.json 2> $O/bench_line_bf16x3.err || true
+W2E_CONV_PRECISION=bf16x3 timeout -k 10 200 python3 tools/layer_bench.py --warm 1.5 --iters 50 > $O/layer_bench_bf16x3.txt 2>&1 || true
+echo bf16x3 done
 timeout -k 10 200 python3 tools/layer_bench.py --warm 1.5 --iters 50 > $O/layer_bench.txt 2>&1
 echo layer done
 timeout -k 10 200 python3 tools/mem_bench.py > $O/mem_bench.txt 2>&1
