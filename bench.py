@@ -227,8 +227,8 @@ def main():
                                "share_of_step": ms / (1e3 * dt)}
             if args.conv_precision == "bf16x3":  # opt-in: algorithmic (fp32-conv) FLOPs against the bf16 matrix peak
                 out["roofline"].update({
-                    "kernel": "w2e::modconv_kernel (SAME and all-phase UP tiles: fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16, "
-                              "3.33 issued bf16 FLOPs per algorithmic FLOP; DOWN and low-resolution tiles: fp32 MFMA 32x32x2)",
+                    "kernel": "w2e::modconv_kernel (SAME, all-phase UP and DOWN tiles: fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16, "
+                              "3.33 issued bf16 FLOPs per algorithmic FLOP; low-resolution tiles: fp32 MFMA 32x32x2)",
                     "peak": BF16_MFMA_PEAK_TFLOPS, "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None})
         c2, ms2, by2 = s.get("upfirdn2d", (0, 0.0, 0.0))
         if c2:

@@ -640,6 +640,31 @@ def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, monkeypatch):
         assert not torch.equal(t, t_exact), "the split path did not run (up)"
 
 
+@pytest.mark.parametrize("b,k,n,h,w", [(2, 24, 136, 64, 64), (1, 33, 130, 70, 96)])
+def test_modconv_bf16x3_down(b, k, n, h, w, monkeypatch):
+    """bf16x3 on the DOWN tile (stride-2 conv = the input gradient of the up-sampling layers; taken from 64x64 outputs and 128 output channels up)."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(13 * k + n)
+    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+    scale = (k * 9) ** -0.5
+    xb = torch.randn(b, k, 2 * h + 1, 2 * w + 1, generator=g).to(DEV)
+    s_in = (torch.randn(b, k, generator=g) * 0.3 + 1).to(DEV)
+    s_out = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    fwd = K.conv_pack(wt, scale, False, False)
+    ref = F.conv2d(xb.double() * s_in.double()[:, :, None, None], wt.double() * scale, stride=2) * s_out.double()[:, :, None, None]
+    monkeypatch.delenv("W2E_CONV_PRECISION", raising=False)
+    y_exact, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
+    monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+    y, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
+    assert_close(y, ref, FWD_TOL, "down")
+    assert not torch.equal(y, y_exact), "the split path did not run (down)"
+    dw = torch.randn(b, n, h, w, generator=g).to(DEV)
+    y, dot = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w, dot_with=dw)
+    assert_close(y, ref, FWD_TOL, "down (dot epilogue) y")
+    assert_close(dot, (ref / s_out.double()[:, :, None, None] * dw.double()).sum((2, 3)), 5e-4, "dot_out")
+
+
 def test_generator1024_golden_with_bf16x3(monkeypatch):
     """The FFHQ-1024 generator against the values captured from the reference with the opt-in bf16x3 conv tiles: the
     north_star tolerance (1e-3 relative) holds through the 17 stacked layers."""

@@ -839,8 +839,8 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
         static size_t allowed = 0;
         if (lds > allowed &&
             hipFuncSetAttribute((const void*)modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
-            allowed = 150 * 1024;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
+            allowed = 160 * 1024;
     }
     modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA><<<grid, 64 * WO * WP, lds, s>>>(p);
 }
@@ -849,6 +849,14 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
 static bool dma_has_cfg(bool all_phase, int cfg) {
     return all_phase ? (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 11)
                      : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10);
+}
+
+// opt-in bf16x3 form: the DOWN tile
+template <int EPI>
+static bool launch_x3_down(int cfg, const ConvParams& p, int grid, size_t lds, hipStream_t s) {
+    if (cfg != 9) return false;
+    launch_cfg<W2E_CONV_DOWN, EPI, 2, 2, 2, 4, 8, 2>(p, grid, lds, s);
+    return true;
 }
 
 // opt-in bf16x3 form: the all-phase UP tiles
@@ -1076,6 +1084,12 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
             use_all = true, best = best_a, best_splits = best_a_splits, best_cost = best_a_cost;
         }
     }
+    // W2E_CONV_PRECISION=bf16x3 (read at every call; opt-in, default = exact fp32 MFMA): the SAME, all-phase UP and DOWN tiles
+    // of the DMA pipeline compute each fp32 product as three bf16 products (see DMA == 2 in the kernel)
+    const char* prec_env = getenv("W2E_CONV_PRECISION");
+    const int tune_x3 = (prec_env && strcmp(prec_env, "bf16x3") == 0) ? 1 : 0;
+    // DOWN in that mode: the 128x256 tile (9) is the one whose stride-2 patch fits beside the bf16 operand images in LDS (156 KB)
+    if (tune_x3 == 1 && mode == W2E_CONV_DOWN && (int64_t)h * w >= 4096 && n_ch >= 128 && best >= 0) best = 9, best_splits = 1;  // (N = 64 fills half the tile: slower than fp32)
     if (const char* sk = getenv("W2E_TUNE_SKIP")) p.tune_skip = atoi(sk);
     if (const char* force = getenv("W2E_TUNE_CFG")) {  // tuning aid (tools/layer_bench.py): "<cfg>[,<splits>[,<mode>]]"
         int fc = -1, fs = 1, fm = -1;  // optional third field: only launches of that mode
@@ -1119,11 +1133,13 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     size_t lds = (up && !use_all) ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
                                   : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
     if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
-    // W2E_CONV_PRECISION=bf16x3 (read at every call; opt-in, default = exact fp32 MFMA): the SAME-mode tiles of the DMA
-    // pipeline compute each fp32 product as three bf16 products (see DMA == 2 in the kernel)
-    const char* prec_env = getenv("W2E_CONV_PRECISION");
-    const int tune_x3 = (prec_env && strcmp(prec_env, "bf16x3") == 0) ? 1 : 0;
     bool use_x3 = false;
+    if (tune_x3 == 1 && !use_dma && mode == W2E_CONV_DOWN && best == 9) {  // DOWN: not a DMA tile by default
+        const int plane16 = (p.plane + 15) & ~15;
+        const int slots = (int)ceil_div(4 * plane16, nt_best);
+        const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
+        if (off_ok && slots <= 4 * max_patch_slots(mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
+    }
     if (tune_x3 == 1 && !use_dma && mode == W2E_CONV_SAME && best == 8 && dma_has_cfg(false, best)) {  // the 32x512 tile: not a DMA tile by default
         const int plane16 = (p.plane + 15) & ~15;
         const int slots = (int)ceil_div(4 * plane16, nt_best);
@@ -1136,14 +1152,16 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
         if (off_ok && slots <= 4 * max_patch_slots(W2E_CONV_UP, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
     }
-    if (tune_x3 == 1 && use_dma && ((mode == W2E_CONV_SAME && (best <= 2 || best == 8)) || (use_all && (best <= 2 || best == 11)))) {
+    if (tune_x3 == 1 && use_dma && ((mode == W2E_CONV_SAME && (best <= 2 || best == 8)) || (use_all && (best <= 2 || best == 11)) ||
+                                    (mode == W2E_CONV_DOWN && best == 9))) {
         // fp32 staging area + bf16 operand images (20*tn + 2*plane 16-byte entries) + the in_scale table
         lds_dma = sizeof(float) * (((size_t)kc * 9 * tn + (size_t)kc * p.plane) + 4 * ((size_t)20 * tn + 2 * (size_t)p.plane) + (size_t)((k_ch + 7) / 8) * 8);
-        use_x3 = lds_dma <= 150 * 1024;
+        use_x3 = lds_dma <= 160 * 1024;
+        if (!use_x3 && mode == W2E_CONV_DOWN) use_dma = false;  // (DOWN takes the DMA pipeline only for this mode)
         if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "  bf16x3: %s (%zu B LDS)\n", use_x3 ? "yes" : "no", lds_dma);
     }
     if (use_dma) lds = lds_dma;
-    W2E_REQUIRE(lds <= 150 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
+    W2E_REQUIRE(lds <= 160 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
     const int k_gran = use_all ? kc : kc_max;
     p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), k_gran) * k_gran);
     p.splits = (int)ceil_div(k_ch, p.k_per);
@@ -1176,6 +1194,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     bool ok = false;
     if (use_x3 && use_all) {
         ok = launch_x3_up(best, p, (int)grid, lds, s);
+    } else if (use_x3 && mode == W2E_CONV_DOWN) {
+        if (dot_with) ok = launch_x3_down<EPI_DOT>(best, p, (int)grid, lds, s);
+        else ok = launch_x3_down<EPI_PLAIN>(best, p, (int)grid, lds, s);
     } else if (use_x3) {
         if (act && p.splits == 1) ok = launch_x3<EPI_ACT>(best, p, (int)grid, lds, s);
         else if (dot_with) ok = launch_x3<EPI_DOT>(best, p, (int)grid, lds, s);
