@@ -15,9 +15,9 @@ echo layer done
 timeout -k 10 200 python3 tools/mem_bench.py > $O/mem_bench.txt 2>&1
 echo mem done
 timeout -k 10 60 tools/bin/mfma_peak > $O/mfma_peak.txt 2>&1 || true
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --spinup 0 --no-cpu-baseline > $O/bench_stats.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --spinup 0 --no-preview --no-cpu-baseline > $O/bench_stats.log 2>&1
 echo stats done
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 2 --warmup 1 --spinup 0 --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 2 --warmup 1 --spinup 0 --no-preview --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
 echo fetch done
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --steps 2 --warmup 1 --spinup 0 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --steps 2 --warmup 1 --spinup 0 --no-preview --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
 echo write done

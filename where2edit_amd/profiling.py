@@ -10,6 +10,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []  # (name, work, start_event, end_event)
+        self.enabled = True  # the caller may switch spans off for some steps (a timed event record costs ~8 us of GPU time)
 
     def __enter__(self):
         global _active
@@ -45,4 +46,4 @@ class _Span:
 
 def span(name, work=0.0):
     """Returns an object whose .end() closes the span, or None when timing is off."""
-    return _Span(name, work) if _active is not None else None
+    return _Span(name, work) if (_active is not None and _active.enabled) else None
