@@ -2,7 +2,10 @@
 """Headline benchmark: 1024^2 edited images/s per StyleCLIP-mapper training step (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N>1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plain `python bench.py --gpus N`: the
+    parent then starts N worker processes itself, one per GPU, BEFORE it touches the GPU (the reference's
+    mp.spawn, attention/run_attention.py:913-919), relays rank 0's JSON line and exits with the workers' status.
 
 One "step" = one iteration of mapper/training/coach.py:79-92 on this rank's shard of synthetic
 FFHQ-shape W+ latents: G(w) [no grad] -> w_hat = w + 0.1 M(w) -> G(w_hat) -> CLIP loss + latent L2 ->
@@ -91,6 +94,18 @@ def pmc_traffic():
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(size):
     """The oracle's mapper step (oracle/step.py, a port of coach.py:79-92 on stock CPU torch ops) at batch 1
     on this box's host cores: one full step (2 G forwards + CLIP + backward + Ranger).  Bounded sample."""
@@ -121,9 +136,67 @@ def cpu_baseline(size):
         grads = torch.autograd.grad(loss, params)
         st.step(params, grads)
     dt = time.perf_counter() - t0
-    return {"value": n_steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+    # one more step on ONE thread (SURVEY 8d asks for the single-core figure beside the all-core one), and
+    # BASELINE configs[0] (the reference's own CPU-runnable case: 256^2 generator forward, one latent) on all cores
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    loss, _, _, _, _ = ostep.mapper_step_loss(gsd, msd, csd, w, tokens, size=size, clip_lambda=1.0, latent_l2_lambda=0.8)
+    st.step(params, torch.autograd.grad(loss, params))
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(cores)
+    g256, w256 = seeded.generator_state_dict(256), seeded.wplus_latents(1, og.n_latent(256), salt=3)
+    with torch.no_grad():
+        og.generator_forward(g256, [w256], size=256, input_is_latent=True, randomize_noise=False)
+        t2 = time.perf_counter()
+        og.generator_forward(g256, [w256], size=256, input_is_latent=True, randomize_noise=False)
+        dt2 = time.perf_counter() - t2
+    return {"value": n_steps / dt, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "one_thread": {"value": 1.0 / dt1, "unit": "images/s", "cores": 1, "sample": f"1 mapper step, batch 1, {size}^2, {dt1:.1f} s"},
+            "config0_g256_forward": {"value": 1.0 / dt2, "unit": "images/s", "cores": cores,
+                                     "sample": f"StyleGAN2-256 generator forward, 1 latent (BASELINE configs[0]), {dt2:.2f} s"},
             "sample": f"{n_steps} mapper steps (each 2 G fwd + CLIP ViT-B/32 fwd/bwd + G bwd + Ranger), batch 1, {size}^2, "
                       f"oracle/ on torch {torch.__version__} CPU ops, {cores} threads, {dt:.1f} s"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks from here.  Nothing in this process has
+    touched the GPU (no HIP call, not even torch.cuda.is_available()), and the workers are fresh interpreters -- a process
+    that has initialised the GPU is never replaced or forked."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
+def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0):
+    """Untimed full steps until the last `window` step times agree within `tol` ((max-min)/mean): a fresh box leaves its idle
+    clocks, caches / allocator pools / lazily built packs settle.  Independent of --warmup, so the timed region starts at
+    steady state whatever the caller asks for (round 1 lost 10 % of its headline to a 5-step warm-up)."""
+    times = []
+    t_begin = time.perf_counter()
+    while len(times) < max_steps and time.perf_counter() - t_begin < max_seconds:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_fn()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        last = times[-window:]
+        if len(last) == window and (max(last) - min(last)) <= tol * (sum(last) / window):
+            return len(times), True
+    return len(times), False
 
 
 def main():
@@ -142,9 +215,9 @@ def main():
                     help="the roofline's HIP events are recorded on every N-th timed step (166 timed event records per step "
                          "cost the step 5 %%: 159 images/s without them, 150 with them on every step)")
     ap.add_argument("--no-preview", action="store_true", help="skip the extra K steps in the opt-in bf16x3 conv precision (N=1 only)")
-    ap.add_argument("--spinup", type=float, default=0.7,
-                    help="seconds of untimed G(w) forwards before the W warm-up steps: brings a fresh box's GPU out of its "
-                         "idle clocks even when the caller asks for only a few warm-up steps (reported in config)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank; default) or gloo (self-test: the ranks may share a GPU)")
+    ap.add_argument("--no-stabilise", action="store_true", help="skip the untimed steady-state loop before the warm-up steps")
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"],
                     help="f32 (default): exact fp32 MFMA everywhere.  bf16x3: the SAME-resolution and up-sampling conv tiles compute each fp32 "
                          "product as three bf16 products (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product; every "
@@ -153,16 +226,25 @@ def main():
                     help="BASELINE configs index + 1: 2 = clip_loss mapper step (the headline, default); 3 = the same step with "
                          "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8)")
     args = ap.parse_args()
-    if args.conv_precision != "f32":
-        os.environ["W2E_CONV_PRECISION"] = args.conv_precision  # read by libw2e.so at every conv launch
+    tune = sorted(k for k in os.environ if k.startswith("W2E_TUNE_"))
+    if tune:  # the tuning aids can skip work or force slow tiles: never measure with them set
+        raise SystemExit(f"bench.py refuses to run with tuning variables set: {', '.join(tune)}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
+    from where2edit_amd import _lib
     from where2edit_amd import dist as wd
     from where2edit_amd import profiling
-    rank, world, local = wd.init_from_env()
+    rank, world, local = wd.init_from_env(backend=args.dist_backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = f"cuda:{local}"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and world > n_dev:
+        raise SystemExit(f"--gpus {world} but this node has {n_dev} GPU(s) (RCCL wants one device per rank; --dist-backend gloo "
+                         "lets ranks share a GPU for a self-test)")
+    device = f"cuda:{local % max(n_dev, 1)}"
     torch.cuda.set_device(device)
+    _lib.set_option("conv_precision", args.conv_precision)
     coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend, args.workload)
     w = synthetic_latents(coach.net.decoder, args.batch, rank)
     mask = None
@@ -175,11 +257,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup:  # clock ramp only: no state of the step is touched
-        with torch.no_grad():
-            coach.net.decoder([w], input_is_latent=True, randomize_noise=False, truncation=1)
-        torch.cuda.synchronize()
+    stab_steps, stab_ok = (0, False) if args.no_stabilise else stabilise(lambda: coach.train_step(w, mask))
     for _ in range(args.warmup):
         coach.train_step(w, mask)
     barrier()
@@ -221,7 +299,7 @@ def main():
                                 f"+ clip_loss + id_loss (IR-SE50, stock ops), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
                    "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
-                   "spinup_s": args.spinup},
+                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "dist_backend": args.dist_backend if world > 1 else None},
     }
     if timer is not None:
         s = timer.summary()
@@ -249,9 +327,9 @@ def main():
             stack_tflops = 3 * G_FWD_GFLOP_1024 * 1e9 * global_batch * args.steps / dt / 1e12 / world
             out["stack_mfma_frac_of_step"] = stack_tflops / FP32_MFMA_PEAK_TFLOPS
     if world == 1 and args.conv_precision == "f32" and not args.no_preview:
-        # the same K steps once more with the opt-in conv precision (the library reads the variable at every launch):
+        # the same K steps once more with the opt-in conv precision (w2e_set_option):
         # reported beside the headline, never as `value`
-        os.environ["W2E_CONV_PRECISION"] = "bf16x3"
+        _lib.set_option("conv_precision", "bf16x3")
         for _ in range(5):
             coach.train_step(w, mask)
         barrier()
@@ -260,7 +338,7 @@ def main():
             last2 = coach.train_step(w, mask)
         barrier()
         dt2 = time.perf_counter() - t1
-        os.environ.pop("W2E_CONV_PRECISION", None)
+        _lib.set_option("conv_precision", "f32")
         out["bf16x3_preview"] = {"value": global_batch * args.steps / dt2, "unit": "images/s", "ms_per_step": 1e3 * dt2 / args.steps,
                                  "dtype": "bf16x3", "final_loss": float(last2["loss"]),
                                  "note": "opt-in --conv-precision bf16x3: each fp32 product of the 3x3 convs as three bf16 MFMA products "

@@ -10,10 +10,19 @@
  * Conventions (all entry points):
  *   - plain C, no torch types; every pointer is a DEVICE pointer to contiguous fp32
  *     (NCHW for images) unless stated; the CALLER allocates outputs and workspaces;
- *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it,
- *     never synchronises, never allocates (safe under hipGraph capture);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *     never synchronises and never allocates device memory (safe under hipGraph capture
+ *     once each kernel has been launched once on the device: the first launch of a kernel
+ *     that needs > 64 KB of LDS calls hipFuncSetAttribute for that device);
+ *   - all pointers of one call must belong to the CURRENT HIP device (hipSetDevice), which
+ *     must also own `stream`;
  *   - returns 0 on success, non-zero on error; w2e_last_error() then describes it
- *     (thread-local); nothing throws across the ABI; no global mutable state.
+ *     (thread-local); nothing throws across the ABI;
+ *   - global mutable state: the error string (thread-local), the process-wide options below
+ *     (read from the environment ONCE when the library is loaded, then only changed by
+ *     w2e_set_option; no getenv on any launch path), and one "large LDS enabled" bit per
+ *     (kernel, device).  Work-skipping / clock-stamping tuning aids (tune_skip, tune_clock)
+ *     exist only in a library compiled with -DW2E_TUNING; the shipped build ignores them.
  */
 #ifndef W2E_H
 #define W2E_H
@@ -25,10 +34,21 @@
 extern "C" {
 #endif
 
-#define W2E_VERSION 1
+#define W2E_VERSION 2
 
 int w2e_version(void);
 const char* w2e_last_error(void);
+
+/* Process-wide options.  Names (environment variable read at load in brackets):
+ *   "conv_precision" [W2E_CONV_PRECISION]  "f32" (default: exact fp32 MFMA) | "bf16x3" (opt-in)
+ *   "deterministic"  [W2E_DETERMINISTIC]   "1": bit-reproducible results -- no fp32 atomics anywhere (no split-K,
+ *                                          ordered reductions), the counterpart of the reference's
+ *                                          cudnn.deterministic=True (attention/run_attention.py:903-904)
+ *   "tune_cfg" [W2E_TUNE_CFG] "<cfg>[,<splits>[,<mode>]]" force a conv tile (tests, tools/layer_bench.py); "" = off
+ *   "tune_upall", "tune_dma", "tune_fuse", "tune_print", "tune_blur", "tune_gemm_s": kernel-selection aids
+ * w2e_get_option reads "conv_precision", "deterministic", "tune_cfg", "tuning_build" (1 = compiled with -DW2E_TUNING). */
+int w2e_set_option(const char* name, const char* value);
+int w2e_get_option(const char* name, int* value);
 
 /* ---- K2  upfirdn2d  (models/stylegan2/op/upfirdn2d.py:11-60) ---------------------------
  * y[p,oy,ox] = sum_{ky,kx} kern'[ky,kx] * xz[p, oy*down + ky - pad_y0, ox*down + kx - pad_x0]

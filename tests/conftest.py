@@ -21,3 +21,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def w2e_opt():
+    """Setter for the library's process-wide options (w2e_set_option); everything it touched is reset afterwards."""
+    from where2edit_amd import _lib
+    touched = set()
+    env_default = {"conv_precision": os.environ.get("W2E_CONV_PRECISION", "f32"), "deterministic": os.environ.get("W2E_DETERMINISTIC", "0")}
+
+    def set_(name, value):
+        touched.add(name)
+        _lib.set_option(name, value)
+
+    yield set_
+    for name in touched:
+        _lib.set_option(name, env_default.get(name, ""))

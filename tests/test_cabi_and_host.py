@@ -41,7 +41,14 @@ def test_ctypes_prototypes_cover_the_header():
 
 
 def test_version_and_argument_errors_do_not_need_a_gpu(lib):
-    assert lib.w2e_version() == 1
+    assert lib.w2e_version() == 2
+    # options: read from the environment once at load, then only through the ABI; unknown names are refused
+    assert lib.w2e_set_option(b"deterministic", b"1") == 0
+    v = ctypes.c_int(-1)
+    assert lib.w2e_get_option(b"deterministic", ctypes.byref(v)) == 0 and v.value == 1
+    assert lib.w2e_set_option(b"deterministic", b"0") == 0
+    assert lib.w2e_set_option(b"no_such_option", b"1") != 0
+    assert lib.w2e_get_option(b"tuning_build", ctypes.byref(v)) == 0 and v.value == 0  # the shipped library cannot skip work
     lib.w2e_last_error.restype = ctypes.c_char_p
     # argument validation happens before any HIP call: a null tensor is refused with a message
     rc = lib.w2e_clip_preproc_fwd(None, None, ctypes.c_int64(1), 1024, None)
@@ -149,3 +156,49 @@ def test_irse50_backbone_matches_reference_fixture():
     with torch.no_grad():
         l_same, zero = loss_mod(a, a)
     assert abs(float(l_same)) < 1e-5 and zero == 0
+
+
+def test_trainable_conv_weight_is_refused_not_silently_ignored():
+    """There is no conv-weight gradient kernel (the decoder is frozen on this path, coach.py:174-180): a 3x3 weight that
+    requires grad must raise instead of training 'partially'.  The check runs before any GPU call."""
+    from where2edit_amd.stylegan2 import ModulatedConv2d, StyledConv, freeze_conv_weights
+    x, w = torch.randn(1, 8, 4, 4), torch.randn(1, 512)
+    for m in (ModulatedConv2d(8, 8, 3, 512), StyledConv(8, 8, 3, 512)):
+        with pytest.raises(RuntimeError, match="no conv-weight gradients"):
+            m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
+        freeze_conv_weights(m)
+        assert m.noise.weight.requires_grad if isinstance(m, StyledConv) else m.modulation.weight.requires_grad
+        with pytest.raises(RuntimeError, match="GPU only"):  # past the guard now: the kernels refuse CPU tensors
+            m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
+
+
+def test_text_feature_cache_is_keyed_on_contents_not_addresses():
+    """encode_text_cached must not return a previous prompt's features when a new token tensor lands on a recycled
+    address, and must forget everything on load_state_dict."""
+    from make_golden import CLIP_TINY as c
+    from where2edit_amd.clip_vit import CLIP
+    clip = CLIP(embed_dim=c["embed_dim"], vision_layers=c["vision_layers"], vision_width=c["vision_width"],
+                context_length=c["context_length"], vocab_size=c["vocab_size"], transformer_width=c["text_width"],
+                transformer_heads=1, transformer_layers=c["text_layers"])
+    clip.load_state_dict(seeded.clip_state_dict(**c), strict=True)
+    n = c["context_length"]
+    t1 = torch.zeros(1, n, dtype=torch.int64)
+    t1[0, :3] = torch.tensor([5, 6, c["vocab_size"] - 1])
+    f1 = clip.encode_text_cached(t1).clone()
+    assert clip.encode_text_cached(t1) is clip._text_cache[3]
+    t2 = t1.clone()
+    t2[0, 1] = 9
+    f2 = clip.encode_text_cached(t2)
+    assert not torch.equal(f1, f2) and torch.equal(f2, clip.encode_text(t2))
+    t2[0, 1] = 6  # in-place edit back to prompt 1: same object, new version
+    assert torch.allclose(clip.encode_text_cached(t2), f1)
+    clip.load_state_dict(clip.state_dict())
+    assert clip._text_cache is None
+
+
+def test_bench_refuses_tuning_variables():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=dict(os.environ, W2E_TUNE_SKIP="2"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "W2E_TUNE_SKIP" in (r.stderr + r.stdout)

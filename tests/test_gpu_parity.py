@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import seeded
+from where2edit_amd.stylegan2 import freeze_conv_weights
 from helpers import assert_close, assert_grad_close, golden, rel_err
 from make_golden import MODCONV_CASES, UPFIRDN_CASES, _kernel, modconv_inputs
 from oracle import ops as O
@@ -109,7 +110,7 @@ def _our_modconv(cin, cout, k, demod, up, i):
     if up:
         sd["blur.kernel"] = seeded.fir_kernel(gain=4.0)
     m.load_state_dict(sd, strict=True)
-    return m.to(DEV)
+    return freeze_conv_weights(m.to(DEV))
 
 
 @pytest.mark.parametrize("case", MODCONV_CASES, ids=[c[0] for c in MODCONV_CASES])
@@ -169,7 +170,7 @@ def test_styled_conv_vs_oracle(cin, cout, h, up):
     # HIP
     m = StyledConv(cin, cout, 3, 512, upsample=up)
     m.load_state_dict(sd, strict=True)
-    m = m.to(DEV)
+    m = freeze_conv_weights(m.to(DEV))
     xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
     y, s = m(xg, wg, noise=cu(noise))
     assert_close(y, yo, FWD_TOL, "y")
@@ -246,7 +247,7 @@ def _gen(size, cls=None):
     from where2edit_amd.stylegan2 import Generator
     g = (cls or Generator)(size, 512, 8)
     g.load_state_dict(seeded.generator_state_dict(size), strict=True)
-    return g.to(DEV).eval()
+    return freeze_conv_weights(g.to(DEV).eval())
 
 
 def test_generator16_golden_all_modes():
@@ -352,7 +353,7 @@ def test_empty_batch_passes_through():
     k = cu(O.make_kernel((1, 3, 3, 1)))
     assert upfirdn2d(torch.empty(0, 3, 8, 8, device=DEV), k, up=2, pad=(2, 1)).shape == (0, 3, 16, 16)
     assert fused_leaky_relu(torch.empty(0, 4, device=DEV), torch.zeros(4, device=DEV)).shape == (0, 4)
-    m = StyledConv(8, 8, 3, 512, upsample=True).to(DEV)
+    m = freeze_conv_weights(StyledConv(8, 8, 3, 512, upsample=True).to(DEV))
     y, s = m(torch.empty(0, 8, 4, 4, device=DEV), torch.empty(0, 512, device=DEV), noise=torch.zeros(1, 1, 8, 8, device=DEV))
     assert y.shape == (0, 8, 8, 8) and s.shape == (0, 1, 8, 1, 1)
     r = ToRGB(8, 512, upsample=False).to(DEV)
@@ -522,7 +523,7 @@ def test_modconv_abi_non_square_and_ragged_channels(b, k, n, h, w):
 
 @pytest.mark.parametrize("cfg", [0, 1, 2])
 @pytest.mark.parametrize("b,k,n,h,w", [(2, 20, 40, 37, 53), (1, 8, 8, 70, 33), (2, 33, 130, 16, 100)])
-def test_modconv_lds_dma_pipeline_on_ragged_shapes(cfg, b, k, n, h, w, monkeypatch):
+def test_modconv_lds_dma_pipeline_on_ragged_shapes(cfg, b, k, n, h, w, w2e_opt):
     """The LDS-DMA K-loop pipeline (the 512-thread tiles; picked by the cost model only for the large layers) forced onto
     shapes with ragged channel counts, odd sizes and partial tiles: the zero padding there is entirely the buffer range
     check of `buffer_load ... lds` (halo pixels, channels >= K, weight groups past K).  SAME plain / fused activation / dot
@@ -539,7 +540,7 @@ def test_modconv_lds_dma_pipeline_on_ragged_shapes(cfg, b, k, n, h, w, monkeypat
     so = s_out.double()[:, :, None, None]
     ref = F.conv2d(xd, wd, padding=1) * so
     fwd = K.conv_pack(wt, scale, False, False)
-    monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,0")  # SAME launches only; read by the library at every call
+    w2e_opt("tune_cfg", f"{cfg},1,0")  # SAME launches only (w2e_set_option)
     y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
     assert_close(y, ref, FWD_TOL, "same")
     y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, None, None, h, w)  # no modulation: the in_scale table is all ones
@@ -554,7 +555,7 @@ def test_modconv_lds_dma_pipeline_on_ragged_shapes(cfg, b, k, n, h, w, monkeypat
     assert_close(y, ref, FWD_TOL, "same (dot epilogue) y")
     assert_close(dot, (ref / so * dw.double()).sum((2, 3)), 5e-4, "dot_out")
     if cfg <= 1:  # all-phase UP tiles 0 / 1 (tile 1 takes the pipeline from K >= 256 on: covered by the full-size tests)
-        monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,1")
+        w2e_opt("tune_cfg", f"{cfg},1,1")
         wt_t = torch.randn(k, n, 3, 3, generator=g).to(DEV)
         up = K.conv_pack(wt_t.permute(1, 0, 2, 3).contiguous(), scale, False, False)
         t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
@@ -595,7 +596,7 @@ def test_to_rgb_passthrough_joins_gradients(cin, h, with_skip):
 
 @pytest.mark.parametrize("b,k,n,h,w,cfg", [(2, 20, 40, 37, 53, 0), (1, 8, 8, 70, 33, 1), (2, 33, 130, 16, 100, 2), (1, 24, 32, 40, 64, 8),
                                             (1, 256, 256, 64, 64, 0)])
-def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, monkeypatch):
+def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, w2e_opt):
     """Opt-in W2E_CONV_PRECISION=bf16x3: the SAME-mode tiles of the DMA pipeline compute each fp32 product as three bf16
     products (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, two taps per MFMA).  Same bar as the exact path:
     FWD_TOL = 1e-4 relative against float64 convolutions (north_star: 1e-3), plain / fused activation / dot epilogue,
@@ -613,8 +614,8 @@ def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, monkeypatch):
     ref = F.conv2d(xd, wd, padding=1) * so
     fwd = K.conv_pack(wt, scale, False, False)
     y_exact, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
-    monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,0")
-    monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+    w2e_opt("tune_cfg", f"{cfg},1,0")
+    w2e_opt("conv_precision", "bf16x3")
     y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
     assert_close(y, ref, FWD_TOL, "same")
     assert not torch.equal(y, y_exact), "the split path did not run"
@@ -628,20 +629,20 @@ def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, monkeypatch):
     assert_close(y, ref, FWD_TOL, "same (dot epilogue) y")
     assert_close(dot, (ref / so * dw.double()).sum((2, 3)), 5e-4, "dot_out")
     if cfg <= 2 and h * w >= 256:  # the all-phase UP tiles (two taps of the same output phase per MFMA)
-        monkeypatch.setenv("W2E_TUNE_CFG", f"{cfg},1,1")
+        w2e_opt("tune_cfg", f"{cfg},1,1")
         wt_t = torch.randn(k, n, 3, 3, generator=g).to(DEV)
         up = K.conv_pack(wt_t.permute(1, 0, 2, 3).contiguous(), scale, False, False)
         ref_t = F.conv_transpose2d(xd, wt_t.double() * scale, stride=2) * so
-        monkeypatch.delenv("W2E_CONV_PRECISION")
+        w2e_opt("conv_precision", "f32")
         t_exact, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
-        monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+        w2e_opt("conv_precision", "bf16x3")
         t, _ = K._modconv_raw(K.MODE_UP, x, up, s_in, s_out, h, w)
         assert_close(K.unplanar(t, w), ref_t, FWD_TOL, "up")
         assert not torch.equal(t, t_exact), "the split path did not run (up)"
 
 
 @pytest.mark.parametrize("b,k,n,h,w", [(2, 24, 136, 64, 64), (1, 33, 130, 70, 96)])
-def test_modconv_bf16x3_down(b, k, n, h, w, monkeypatch):
+def test_modconv_bf16x3_down(b, k, n, h, w, w2e_opt):
     """bf16x3 on the DOWN tile (stride-2 conv = the input gradient of the up-sampling layers; taken from 64x64 outputs and 128 output channels up)."""
     import torch.nn.functional as F
     from where2edit_amd import functional as K
@@ -653,9 +654,9 @@ def test_modconv_bf16x3_down(b, k, n, h, w, monkeypatch):
     s_out = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
     fwd = K.conv_pack(wt, scale, False, False)
     ref = F.conv2d(xb.double() * s_in.double()[:, :, None, None], wt.double() * scale, stride=2) * s_out.double()[:, :, None, None]
-    monkeypatch.delenv("W2E_CONV_PRECISION", raising=False)
+    w2e_opt("conv_precision", "f32")
     y_exact, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
-    monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+    w2e_opt("conv_precision", "bf16x3")
     y, _ = K._modconv_raw(K.MODE_DOWN, xb, fwd, s_in, s_out, h, w)
     assert_close(y, ref, FWD_TOL, "down")
     assert not torch.equal(y, y_exact), "the split path did not run (down)"
@@ -665,11 +666,11 @@ def test_modconv_bf16x3_down(b, k, n, h, w, monkeypatch):
     assert_close(dot, (ref / s_out.double()[:, :, None, None] * dw.double()).sum((2, 3)), 5e-4, "dot_out")
 
 
-def test_generator1024_golden_with_bf16x3(monkeypatch):
+def test_generator1024_golden_with_bf16x3(w2e_opt):
     """The FFHQ-1024 generator against the values captured from the reference with the opt-in bf16x3 conv tiles: the
     north_star tolerance (1e-3 relative) holds through the 17 stacked layers."""
     from where2edit_amd.attention_model import Generator as AttGenerator
-    monkeypatch.setenv("W2E_CONV_PRECISION", "bf16x3")
+    w2e_opt("conv_precision", "bf16x3")
     size = 1024
     g = golden("generator_big")
     gen = _gen(size, AttGenerator)

@@ -234,3 +234,191 @@ def test_stylespace_step_matches_oracle():
     flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
     flat_o = torch.cat([g.reshape(-1) for g in grads_o])
     assert_grad_close(flat_h, flat_o, "S-space mapper gradients")
+
+
+def test_bench_workload2_step_matches_oracle(capfd):
+    """The configuration the headline is measured on, as one step: bench.py's workload 2 -- FFHQ-1024, batch 4, LevelsMapper,
+    the full ViT-B/32 critic, random-init weights with the bench's noise-strength / bias perturbation, the bench's
+    synthetic latents -- against oracle.step.mapper_step_loss on the same state_dicts: x, x_hat, the loss terms and the
+    mapper gradients.  Also records which conv tile / split-K the library picks for every launch of that step
+    (gpurun_out/bench_cfg_selections.txt; the selection depends on the batch)."""
+    import bench
+    from where2edit_amd import _lib
+    size, batch = 1024, 4
+    coach = bench.build_coach(size, batch, DEV, False, "hip", 2)
+    w = bench.synthetic_latents(coach.net.decoder, batch, 0)
+    gsd = {k: v.detach().cpu() for k, v in coach.net.decoder.state_dict().items()}
+    csd = {k: v.detach().cpu() for k, v in coach.clip_loss.model.state_dict().items()}
+    osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in coach.net.mapper.state_dict().items()}
+    tokens = coach.text_inputs.cpu()
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    loss_o, terms, x_o, xh_o, wh_o = OS.mapper_step_loss(gsd, osd, csd, w.cpu(), tokens, size=size, clip_lambda=1.0,
+                                                         latent_l2_lambda=0.8)
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    # HIP: forward pieces with the tile selections printed, then the full train_step
+    capfd.readouterr()
+    _lib.set_option("tune_print", 1)
+    try:
+        coach.optimizer.zero_grad()
+        x, x_hat, w_hat = coach.forward_pair(w)
+        loss, _ = coach.calc_loss(w, x, w_hat, x_hat)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("tune_print", 0)
+    sel = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("modconv mode") or ln.startswith("  ")]
+    n_conv = sum(ln.startswith("modconv mode") for ln in sel)
+    assert n_conv == 51, n_conv  # 2 x 17 forward launches + 17 input-gradient launches per step at 1024^2
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "bench_cfg_selections.txt"), "w") as f:
+        f.write(f"# w2e_modconv3x3 tile selections of one bench.py workload-2 step (1024^2, batch {batch}); tune_print\n")
+        f.write("\n".join(sel) + "\n")
+    st = size // 64
+    assert_close(x[:, :, ::st, ::st], x_o[:, :, ::st, ::st], 1e-4, "x = G(w) (strided sample)")
+    assert_close(x_hat, xh_o, 1e-4, "x_hat (all pixels)"), assert_close(w_hat, wh_o, 1e-5, "w_hat")
+    d = coach.train_step(w)
+    assert abs(float(d["loss"]) - loss_o.item()) <= 1e-4 * abs(loss_o.item())
+    assert abs(float(d["loss_clip"]) - terms["loss_clip"].item()) <= 1e-4 * abs(terms["loss_clip"].item())
+    assert abs(float(d["loss_l2_latent"]) - terms["loss_l2_latent"].item()) <= 1e-4 * abs(terms["loss_l2_latent"].item())
+    params = dict(coach.net.mapper.named_parameters())
+    flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
+    flat_o = torch.cat([g.reshape(-1) for g in grads_o])
+    assert_grad_close(flat_h, flat_o, "mapper gradients at the measured configuration")
+
+
+def _region_id_setup(size, s_space=False):
+    from where2edit_amd.attention_model import Generator as AttentionGenerator
+    from where2edit_amd.id_loss import IDLoss
+    loss_mod = IDLoss(types.SimpleNamespace(ir_se50_weights=None))
+    isd = seeded.irse_fill(loss_mod.facenet.state_dict())
+    loss_mod.facenet.load_state_dict(isd, strict=True)
+    opts = _opts(attention_layer=7, id_lambda=0.1, stylegan_size=size, work_in_stylespace=s_space)
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.coach import Coach
+    from where2edit_amd.styleclip_mapper import StyleCLIPMapper
+    net = StyleCLIPMapper(opts)
+    dec = AttentionGenerator(size, 512, 8)
+    gsd = seeded.generator_state_dict(size)
+    dec.load_state_dict(gsd, strict=True)
+    net.decoder = dec
+    c = CLIP_TINY
+    clip = CLIP(embed_dim=c["embed_dim"], vision_layers=c["vision_layers"], vision_width=c["vision_width"],
+                context_length=c["context_length"], vocab_size=c["vocab_size"], transformer_width=c["text_width"],
+                transformer_heads=1, transformer_layers=c["text_layers"])
+    csd = seeded.clip_state_dict(**c)
+    clip.load_state_dict(csd, strict=True)
+    tokens = torch.from_numpy(golden("clip_hf")["tiny.tokens"])[:1]
+    return opts, net, loss_mod, clip, tokens, gsd, csd, isd, Coach, CLIPLoss
+
+
+def test_region_attention_step_with_id_loss_matches_oracle():
+    """BASELINE configs[2] as ONE step: region-attention mask blend + clip_loss + id_loss (id_lambda = 0.1) + latent L2.
+    Generator(256) so that the fused pool-crop-pool kernel (K5b) is the path taken; IR-SE50 with the seeded weights that
+    pin it to the reference's Backbone (tests/golden/irse.npz).  Losses (each term) and the mapper gradients -- which now
+    carry the id term through IR-SE50, K5b, the blend and the generator -- against the oracle (oracle/irse.py)."""
+    from oracle import clip_model as OC
+    from oracle import irse as OI
+    from oracle import mappers as OM
+    size = 256
+    opts, net, loss_mod, clip, tokens, gsd, csd, isd, Coach, CLIPLoss = _region_id_setup(size)
+    msd = seeded.mapper_state_dict(["course_mapping.", "medium_mapping.", "fine_mapping."])
+    net.mapper.load_state_dict(msd, strict=True)
+    coach = Coach(opts, net=net, clip_loss=CLIPLoss(opts, model=clip), id_loss=loss_mod, text_inputs=tokens, device=DEV)
+    w = seeded.wplus_latents(2, OG.n_latent(size), salt=41)
+    mask = (seeded.tensor("region.mask.id", (2, 1, 16, 16)) * 0.5 + 0.5).clamp(0, 1)  # layer 7 of the 256 generator is 16x16
+    # oracle
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    with torch.no_grad():
+        x_o, _, _, feats_o = OG.generator_forward(gsd, [w], size=size, input_is_latent=True, randomize_noise=False, return_features=True)
+    wh_o = w + 0.1 * OM.levels_mapper(osd, w)
+    xh_o, wh_o, _ = OG.generator_forward(gsd, [wh_o], size=size, input_is_latent=True, randomize_noise=False, return_latents=True,
+                                         attention_layer=7, attention_map=mask, feature_map=feats_o)
+    l_id = OI.id_loss(isd, xh_o, x_o)
+    l_clip = OC.clip_loss(csd, xh_o, tokens, size).mean()
+    l_l2 = torch.nn.functional.mse_loss(wh_o, w)
+    loss_o = 0.1 * l_id + l_clip + 0.8 * l_l2
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    # HIP
+    d = coach.train_step(w.to(DEV), mask.to(DEV))
+    for key, ref in (("loss_id", l_id), ("loss_clip", l_clip), ("loss_l2_latent", l_l2), ("loss", loss_o)):
+        assert abs(float(d[key]) - ref.item()) <= 2e-4 * max(abs(ref.item()), 1e-3), (key, float(d[key]), ref.item())
+    params = dict(coach.net.mapper.named_parameters())
+    flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
+    flat_o = torch.cat([g.reshape(-1) for g in grads_o])
+    assert_grad_close(flat_h, flat_o, "mapper gradients (clip + id + l2 through the blend)")
+    # the id term alone (clip and l2 off): its gradient into the mapper, so a wrong id gradient cannot hide behind the others
+    opts2, net2, loss_mod2, clip2, _, _, _, _, _, _ = _region_id_setup(size)
+    opts2.clip_lambda, opts2.latent_l2_lambda, opts2.id_lambda = 0.0, 0.0, 1.0
+    net2.mapper.load_state_dict(msd, strict=True)
+    coach2 = Coach(opts2, net=net2, id_loss=loss_mod2, text_inputs=tokens, device=DEV)
+    osd2 = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    wh2 = w + 0.1 * OM.levels_mapper(osd2, w)
+    xh2, _, _ = OG.generator_forward(gsd, [wh2], size=size, input_is_latent=True, randomize_noise=False, return_latents=True,
+                                     attention_layer=7, attention_map=mask, feature_map=feats_o)
+    l_id2 = OI.id_loss(isd, xh2, x_o)
+    g2 = torch.autograd.grad(l_id2, [osd2[n] for n in names])
+    d2 = coach2.train_step(w.to(DEV), mask.to(DEV))
+    assert abs(float(d2["loss_id"]) - l_id2.item()) <= 2e-4 * max(abs(l_id2.item()), 1e-3)
+    p2 = dict(coach2.net.mapper.named_parameters())
+    assert_grad_close(torch.cat([p2[n].grad.reshape(-1).cpu() for n in names]), torch.cat([g.reshape(-1) for g in g2]),
+                      "mapper gradient of the id term alone")
+
+
+def test_stylespace_region_attention_step_matches_oracle():
+    """The S-space blend sites inside Coach (attention_model.py:573-588, 637-660; run_attention.py:1245): S-space codes,
+    WithoutToRGBStyleSpaceMapper-style per-layer deltas, mask blend at layer 7 -- images and mapper gradients vs the oracle."""
+    from oracle import clip_model as OC
+    from oracle import mappers as OM
+    from where2edit_amd.attention_model import Generator as AttentionGenerator
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.coach import Coach
+    from where2edit_amd.styleclip_mapper import StyleCLIPMapper
+    size = 1024
+    dims = OM.STYLESPACE_DIMENSIONS
+    idx = [c for c in range(len(dims)) if c not in range(1, len(dims), 3)]
+    opts = _opts(work_in_stylespace=True, stylegan_size=size, batch_size=1, attention_layer=13)
+    net = StyleCLIPMapper(opts)
+    gsd = seeded.generator_state_dict(size)
+    dec = AttentionGenerator(size, 512, 8)
+    dec.load_state_dict(gsd, strict=True)
+    net.decoder = dec
+    msd = seeded.mapper_state_dict([f"mapper_{c}." for c in idx], [dims[c] for c in idx])
+    net.mapper.load_state_dict(msd, strict=True)
+    c = CLIP_TINY
+    clip = CLIP(embed_dim=c["embed_dim"], vision_layers=c["vision_layers"], vision_width=c["vision_width"],
+                context_length=c["context_length"], vocab_size=c["vocab_size"], transformer_width=c["text_width"],
+                transformer_heads=1, transformer_layers=c["text_layers"])
+    csd = seeded.clip_state_dict(**c)
+    clip.load_state_dict(csd, strict=True)
+    tokens = torch.from_numpy(golden("clip_hf")["tiny.tokens"])[:1]
+    coach = Coach(opts, net=net, clip_loss=CLIPLoss(opts, model=clip), text_inputs=tokens, device=DEV)
+    w_plus = seeded.wplus_latents(1, OG.n_latent(size), salt=31)
+    with torch.no_grad():
+        _, _, codes = OG.generator_forward(gsd, [w_plus], size=size, input_is_latent=True, randomize_noise=False, return_latents=True)
+    codes = [s.detach() for s in codes]
+    mask = (seeded.tensor("region.mask.s", (1, 1, 64, 64)) * 0.5 + 0.5).clamp(0, 1)
+    osd = {k: v.clone().requires_grad_(True) for k, v in msd.items()}
+    with torch.no_grad():
+        x_o, _, _, feats_o = OG.generator_forward(gsd, [codes], size=size, input_is_stylespace=True, randomize_noise=False,
+                                                  return_features=True)
+    delta = OM.without_torgb_stylespace_mapper(osd, codes)
+    wh_o = [s + 0.1 * dd for s, dd in zip(codes, delta)]
+    xh_o, _, _ = OG.generator_forward(gsd, [wh_o], size=size, input_is_stylespace=True, randomize_noise=False, return_latents=True,
+                                      attention_layer=13, attention_map=mask, feature_map=feats_o)
+    l2_o = sum(torch.nn.functional.mse_loss(a, b) for a, b in zip(wh_o, codes))
+    loss_o = OC.clip_loss(csd, xh_o, tokens, size).mean() + 0.8 * l2_o
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    codes_d = [s.to(DEV) for s in codes]
+    x, x_hat, _ = coach.forward_pair(codes_d, mask.to(DEV))
+    assert_close(x, x_o, 1e-4, "x = G(s)"), assert_close(x_hat, xh_o, 1e-4, "blended x_hat (S-space)")
+    d = coach.train_step(codes_d, mask.to(DEV))
+    assert abs(float(d["loss"]) - loss_o.item()) <= 1e-4 * abs(loss_o.item())
+    params = dict(coach.net.mapper.named_parameters())
+    assert_grad_close(torch.cat([params[n].grad.reshape(-1).cpu() for n in names]), torch.cat([g.reshape(-1) for g in grads_o]),
+                      "S-space mapper gradients through the blend")

@@ -13,9 +13,9 @@ import bench  # noqa: E402
 
 def run(mode):
     if mode == "bf16x3":
-        os.environ["W2E_CONV_PRECISION"] = "bf16x3"
+        _lib.set_option("conv_precision", "bf16x3")
     else:
-        os.environ.pop("W2E_CONV_PRECISION", None)
+        _lib.set_option("conv_precision", "f32")
     torch.manual_seed(0)
     coach = bench.build_coach(1024, 2, "cuda:0", False, "hip", 2)
     w = bench.synthetic_latents(coach.net.decoder, 2, 0)

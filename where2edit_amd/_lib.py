@@ -16,6 +16,8 @@ _F = ctypes.c_float
 _PROTOS = {
     "w2e_version": (_I, []),
     "w2e_last_error": (ctypes.c_char_p, []),
+    "w2e_set_option": (_I, [ctypes.c_char_p, ctypes.c_char_p]),
+    "w2e_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
     "w2e_bias_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
     "w2e_bias_act_bwd": (_I, [_P, _P, _P, _L, _F, _F, _P]),
@@ -58,8 +60,8 @@ def load():
             fn.restype, fn.argtypes = res, args
         from . import _lib_vit  # noqa: F401  (registers the ViT entry points when present)
         _lib_vit.declare(lib)
-        if lib.w2e_version() != 1:
-            raise RuntimeError("libw2e.so version mismatch")
+        if lib.w2e_version() != 2:
+            raise RuntimeError("libw2e.so version mismatch: rebuild with `python -m where2edit_amd.build --force`")
         _lib = lib
     return _lib
 
@@ -67,21 +69,30 @@ def load():
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_cur_dev = torch.cuda.current_device  # (lazy CUDA init happens long before the first kernel call)
+
+
 def stream_ptr():
     """The current HIP stream of the current device as a void*.  (torch.cuda.current_stream() builds a Python Stream
     object per call, ~10 us -- 2 ms of host time per mapper step; the raw accessor is ~0.3 us.)"""
     if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
+        return ctypes.c_void_p(_raw_stream(_cur_dev()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def ptr(t):
-    """Device pointer of a contiguous fp32 CUDA(HIP) tensor, or NULL for None."""
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor, or NULL for None.  The tensor must live on the CURRENT
+    device: the kernels are launched on the current device's stream, and a pointer of another GPU there is a memory
+    fault, not a Python error (wrap multi-device use in `with torch.cuda.device(t.device):`)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("where2edit_amd ops run on the GPU only (got a CPU tensor); the CPU restatement "
                            "is oracle/, for tests")
+    if t.device.index != _cur_dev():
+        raise RuntimeError(f"where2edit_amd: tensor on cuda:{t.device.index} but the current device is cuda:{_cur_dev()} "
+                           "(kernels launch on the current device's stream): call torch.cuda.set_device(...) or use "
+                           "`with torch.cuda.device(t.device):`")
     if t.dtype != torch.float32:
         raise RuntimeError(f"where2edit_amd kernels are fp32 (got {t.dtype})")
     if not t.is_contiguous():
@@ -97,3 +108,19 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.w2e_last_error().decode()}")
+
+
+def set_option(name, value):
+    """w2e_set_option: process-wide library options ("conv_precision", "deterministic", "tune_cfg", ...; include/w2e.h)."""
+    lib = load()
+    v = None if value is None else str(value).encode()
+    if lib.w2e_set_option(name.encode(), v) != 0:
+        raise RuntimeError(lib.w2e_last_error().decode())
+
+
+def get_option(name):
+    lib = load()
+    out = ctypes.c_int(0)
+    if lib.w2e_get_option(name.encode(), ctypes.byref(out)) != 0:
+        raise RuntimeError(lib.w2e_last_error().decode())
+    return out.value

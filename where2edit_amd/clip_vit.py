@@ -146,11 +146,21 @@ class CLIP(nn.Module):
     def encode_text_cached(self, text):
         """The text tower on constant tokens is recomputed every step by the reference (clip_loss.py:16);
         its output cannot change while the weights are frozen, so it is computed once per token tensor."""
-        key = (text.data_ptr(), text._version, tuple(text.shape), str(text.device))
-        if self._text_cache is None or self._text_cache[0] != key:
-            with torch.no_grad():
-                self._text_cache = (key, self.encode_text(text))
-        return self._text_cache[1]
+        c = self._text_cache
+        # fast path: the very same tensor object, unmodified (the cache holds a reference, so its address cannot be
+        # recycled for another prompt); otherwise compare contents with the cached copy (one small D2H sync)
+        if c is not None and ((c[0] is text and c[1] == text._version) or
+                              (c[2].shape == text.shape and c[2].device == text.device and torch.equal(c[2], text))):
+            if c[0] is not text or c[1] != text._version:
+                self._text_cache = (text, text._version, c[2], c[3])
+            return c[3]
+        with torch.no_grad():
+            self._text_cache = (text, text._version, text.detach().clone(), self.encode_text(text))
+        return self._text_cache[3]
+
+    def load_state_dict(self, *args, **kwargs):
+        self._text_cache = None  # new weights: the cached text features are stale
+        return super().load_state_dict(*args, **kwargs)
 
     def forward(self, image, text):
         image_features = self.encode_image(image)

@@ -54,6 +54,7 @@ class Coach:
         # M = 50*B, the 4^2..32^2 layers, [B,512] style math) leave idle: 0-5 % more images/s depending on the device.
         # Off by default: overlapped kernels stretch each other's durations, which blurs per-kernel roofline numbers.
         self._side = torch.cuda.Stream(device=self.device) if os.environ.get("W2E_SIDE_STREAM", "0") == "1" else None
+        self._side_primed = False
 
     def configure_optimizers(self):
         params = list(self.net.mapper.parameters())  # mapper only: the decoder is never optimised (coach.py:174-180)
@@ -70,16 +71,28 @@ class Coach:
         s_space = getattr(self.opts, "work_in_stylespace", False)
         att_layer = getattr(self.opts, "attention_layer", 0)
         if mask is not None and att_layer > 0:
-            if s_space:
-                raise NotImplementedError("region-attention blend with S-space mappers")
             with torch.no_grad():
-                x, _, _, feats = dec([w], input_is_latent=True, randomize_noise=False, truncation=1, return_features=True)
+                x, _, _, feats = dec([w], input_is_latent=True, randomize_noise=False, truncation=1, return_features=True,
+                                     input_is_stylespace=s_space)
             self._x_ready = None
+            if s_space:  # the S-space blend sites of attention_model.py:573-588, 637-660 (run_attention.py:1245)
+                delta = self.net.mapper(w)
+                w_hat = [c + 0.1 * dc for c, dc in zip(w, delta)]
+                x_hat, _, w_hat = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False, truncation=1,
+                                      input_is_stylespace=True, attention_layer=att_layer, attention_map=mask, feature_map=feats)
+                return x, x_hat, w_hat
             w_hat = w + 0.1 * self.net.mapper(w)
             x_hat, w_hat, _ = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False, truncation=1,
                                   attention_layer=att_layer, attention_map=mask, feature_map=feats)
             return x, x_hat, w_hat
         main = torch.cuda.current_stream()
+        if self._side is not None and not self._side_primed:
+            # the decoder's derived-weight caches (conv packs, wsq, stacked affines) are built lazily by the first pass:
+            # build them on the MAIN stream once, so the side-stream pass and G(w_hat) never race on half-written packs
+            with torch.no_grad():
+                dec([w[:1]] if not s_space else [[c[:1] for c in w]], input_is_latent=True, randomize_noise=False, truncation=1,
+                    input_is_stylespace=s_space)
+            self._side_primed = True
         if self._side is not None:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side), torch.no_grad():

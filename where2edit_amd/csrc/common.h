@@ -11,6 +11,28 @@ namespace w2e {
 
 void set_error(const char* fmt, ...);
 
+// Process-wide options (runtime.hip): read from the environment once at library load, changed by w2e_set_option().
+struct Options {
+    int conv_precision;  // 0 = exact fp32 MFMA (default); 1 = bf16x3 (W2E_CONV_PRECISION=bf16x3, opt-in)
+    int deterministic;   // 1 = no fp32 atomics anywhere: ordered reductions, no split-K (W2E_DETERMINISTIC=1)
+    int tune_cfg, tune_cfg_splits, tune_cfg_mode;  // force a conv tile (tests / tools/layer_bench.py); -1 = off
+    int tune_upall, tune_dma, tune_fuse;           // -1 = the library's own choice, 0 never, 1 always
+    int tune_print, tune_blur, tune_gemm_s;
+    int tune_skip, tune_clock;  // only honoured by a -DW2E_TUNING build (they skip work / synchronise)
+};
+const Options& options();
+
+// Kernels that need more than 64 KB of dynamic LDS opt in once per (kernel, device).  Returns true when the current
+// device has the attribute set.  (hipFuncSetAttribute is per device: a process driving several GPUs needs it on each.)
+static inline bool big_lds_once(const void* fn, unsigned* done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
+    if (*done_mask & (1u << dev)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    *done_mask |= 1u << dev;
+    return true;
+}
+
 // Argument check: records the message and makes the entry point return 1.
 #define W2E_REQUIRE(cond, ...)        \
     do {                              \

@@ -4,15 +4,6 @@
 
 namespace w2e {
 
-static thread_local char g_err[512] = "";
-
-void set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
 // ------------------------------------------------------------------------------------- K3
 // x as [outer, C, inner].  VEC4 requires (inner % 4 == 0) or (inner == 1 && C % 4 == 0).
 template <bool VEC4>
@@ -410,8 +401,6 @@ using namespace w2e;
 
 extern "C" {
 
-int w2e_version(void) { return W2E_VERSION; }
-const char* w2e_last_error(void) { return g_err; }
 
 int w2e_bias_act_fwd(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
                      int64_t outer, int64_t channels, int64_t inner, float slope, float gain, void* stream) {

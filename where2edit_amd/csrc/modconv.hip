@@ -67,6 +67,13 @@ enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
 // 4 phases x NPB/4 pixel blocks.  The per-phase form stages the activation patch once per phase (4 patches per 9 taps);
 // this one stages it once, which wins where the patch, not the weights, dominates staging (few channels, many pixels).
 constexpr int CONV_UPALL = 3;
+// The work-skipping / clock-stamping aids exist only in a -DW2E_TUNING build (python -m where2edit_amd.build with
+// W2E_HIPCC_FLAGS=-DW2E_TUNING); the shipped library cannot be told to skip its own work.
+#ifdef W2E_TUNING
+#define W2E_SKIP(p, bit) ((p).tune_skip & (bit))
+#else
+#define W2E_SKIP(p, bit) false
+#endif
 #ifdef W2E_STAMPS  // diagnostic build (W2E_HIPCC_FLAGS=-DW2E_STAMPS): 8 words per workgroup, see the W2E_TUNE_CLOCK report
 constexpr int STAMP_STRIDE = 8;
 #else
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     int bid = blockIdx.x;
     if (is_up(MODE)) {
         if (bid < p.border_wgs) {  // uniform per workgroup
-            if (p.tune_skip & 32) return;  // tuning aid: price the border workgroups
+            if (W2E_SKIP(p, 32)) return;  // tuning aid: price the border workgroups
             if (p.N >= 64) upconv_border<64, NT>(p, smem, bid);
             else upconv_border<32, NT>(p, smem, bid);
             return;
@@ -315,11 +322,13 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     const int ks = bid % p.splits;
     bid /= p.splits;
     const int k_lo = ks * p.k_per;
-    const int k_hi = (p.tune_skip & 2) ? k_lo : ((k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K);
+    const int k_hi = W2E_SKIP(p, 2) ? k_lo : ((k_lo + p.k_per < p.K) ? k_lo + p.k_per : p.K);
+#ifdef W2E_TUNING
     if (p.stamps && tid == 0) {
         p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
         p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -453,14 +462,14 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 
         prefetch(k_lo);
         for (int k0 = k_lo; k0 < k_hi; k0 += KCP) {
-            if (!(p.tune_skip & 4) || k0 == k_lo) {  // tuning aid: bit 2 = stage only the first chunk
+            if (!W2E_SKIP(p, 4) || k0 == k_lo) {  // tuning aid: bit 2 = stage only the first chunk
                 __syncthreads();  // everyone finished reading the previous chunk
                 commit();
                 __syncthreads();
             }
             // the next chunk's loads are issued from inside the MFMA stream; the two waves that share a SIMD (w, w+4 in a
             // 512-thread workgroup) do it at different taps so that one of them always feeds the matrix pipe
-            const bool do_pf = k0 + KCP < k_hi && !(p.tune_skip & 4);
+            const bool do_pf = k0 + KCP < k_hi && !W2E_SKIP(p, 4);
             const int my_pos = (NT == 512) ? (wave >> 2) : 0;
             const float4 no_scale[KCP / 8] = {};
             mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX, false>(acc, ws, xs, a_base, base, p.pw, p.plane, no_scale, [&](int pos) __attribute__((always_inline)) {
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                         v += bs[r] + nz[pb];
                         v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
                     }
-                    if ((p.tune_skip & 1) && v != 123456.789f) continue;  // tuning aid: no stores, arithmetic kept alive
+                    if (W2E_SKIP(p, 1) && v != 123456.789f) continue;  // tuning aid: no stores, arithmetic kept alive
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[pb], soff, 0);
                 }
             }
@@ -801,10 +810,12 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         __syncthreads();
         if (tid < TN && n0 + tid < p.N) atomicAdd(&p.dot_out[(int64_t)b * p.N + n0 + tid], red[tid]);
     }
+#ifdef W2E_TUNING
     if (p.stamps && tid == 0) {
         p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
         p.stamps[STAMP_STRIDE * (int64_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 }
 
 // weight [cout,cin,3,3] -> wp [ceil(K/8)][9][2][N][4]: element (kc, tap, h, n, c) = scale * W(k = 8*kc + 2*c + h, tap', n)
@@ -835,12 +846,9 @@ struct TileCfg {
 
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, int DMA = 0>
 static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s) {
-    if (lds > 64 * 1024) {  // dynamic LDS above 64 KB is opt-in per kernel (gfx950: 160 KB per CU)
-        static size_t allowed = 0;
-        if (lds > allowed &&
-            hipFuncSetAttribute((const void*)modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
-            allowed = 160 * 1024;
+    if (lds > 64 * 1024) {  // dynamic LDS above 64 KB is opt-in per kernel and per device (gfx950: 160 KB per CU)
+        static unsigned done = 0;
+        big_lds_once((const void*)modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA>, &done);
     }
     modconv_kernel<MODE, EPI, NOB, NPB, WO, WP, KC, DMA><<<grid, 64 * WO * WP, lds, s>>>(p);
 }
@@ -997,6 +1005,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     // do not go faster than one after the other); a workgroup's time is its per-SIMD MFMA chain plus the
     // part of its staging (barriers, LDS writes) that the register prefetch cannot hide.
     const bool up = mode == W2E_CONV_UP;
+    const Options& opt = options();
     const TileCfg* cfgs = kCfgStd;
     const int ncfg = kNumCfg;
     const int kc = 8;  // channels per K-chunk = one float4 group per lane-half
@@ -1052,7 +1061,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     bool use_all = false;
     if (up) {
         static const int kAll[] = {0, 1, 2, 4, 8, 11};
-        static const int tune_all = getenv("W2E_TUNE_UPALL") ? atoi(getenv("W2E_TUNE_UPALL")) : -1;  // 0 never, 1 always
+        const int tune_all = opt.tune_upall;  // -1 the library's choice, 0 never, 1 always
         int best_a = -1, best_a_splits = 1;
         double best_a_cost = 0.0;
         for (int ci = 0; ci < 6 && tune_all != 0; ++ci) {
@@ -1084,19 +1093,20 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
             use_all = true, best = best_a, best_splits = best_a_splits, best_cost = best_a_cost;
         }
     }
-    // W2E_CONV_PRECISION=bf16x3 (read at every call; opt-in, default = exact fp32 MFMA): the SAME, all-phase UP and DOWN tiles
+    // conv_precision = bf16x3 (option; opt-in, default = exact fp32 MFMA): the SAME, all-phase UP and DOWN tiles
     // of the DMA pipeline compute each fp32 product as three bf16 products (see DMA == 2 in the kernel)
-    const char* prec_env = getenv("W2E_CONV_PRECISION");
-    const int tune_x3 = (prec_env && strcmp(prec_env, "bf16x3") == 0) ? 1 : 0;
+    const int tune_x3 = opt.conv_precision;
     // DOWN in that mode: the 128x256 tile (9) is the one whose stride-2 patch fits beside the bf16 operand images in LDS (156 KB)
     if (tune_x3 == 1 && mode == W2E_CONV_DOWN && (int64_t)h * w >= 4096 && n_ch >= 128 && best >= 0) best = 9, best_splits = 1;  // (N = 64 fills half the tile: slower than fp32)
-    if (const char* sk = getenv("W2E_TUNE_SKIP")) p.tune_skip = atoi(sk);
-    if (const char* force = getenv("W2E_TUNE_CFG")) {  // tuning aid (tools/layer_bench.py): "<cfg>[,<splits>[,<mode>]]"
-        int fc = -1, fs = 1, fm = -1;  // optional third field: only launches of that mode
-        if (sscanf(force, "%d,%d,%d", &fc, &fs, &fm) >= 1 && fc >= 0 && fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode))
-            best = fc, best_splits = fs > 0 ? fs : 1;
+#ifdef W2E_TUNING
+    p.tune_skip = opt.tune_skip;
+#endif
+    if (opt.tune_cfg >= 0) {  // tests / tools/layer_bench.py: "<cfg>[,<splits>[,<mode>]]", third field: only launches of that mode
+        const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
+        if (fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
-    if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
+    if (opt.deterministic) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
+    if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
     const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * (use_all ? cfg.npb / 4 : cfg.npb) * cfg.wp;
@@ -1116,7 +1126,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     // W2E_TUNE_DMA: 0 never, 1 wherever instantiated; default = where it measured faster (tools/layer_bench.py, batch 4):
     // the 512-thread 8-accumulator SAME tiles (+1.5-3 %) and the all-phase UP tiles 0 / 1 at K >= 256 (+2-3 %); not DOWN (-1-2 %), not the
     // 256-thread 32x512 tile of the 1024^2 layer (two LDS stages leave room for 2 instead of 3 workgroups per CU: -11 %)
-    static const int tune_dma = getenv("W2E_TUNE_DMA") ? atoi(getenv("W2E_TUNE_DMA")) : -1;
+    const int tune_dma = opt.tune_dma;
     bool use_dma = false;
     size_t lds_dma = 0;
     const bool dma_auto = use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
@@ -1127,7 +1137,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         // (the pipeline addresses channels up to K+7 of an image with 32-bit byte offsets: they must not wrap)
         const bool off_ok = ((int64_t)k_ch + 8) * p.in_h * p.in_w * 4 < ((int64_t)1 << 32);
         if (off_ok && lds_dma <= 150 * 1024 && slots <= 4 * max_patch_slots(up ? W2E_CONV_UP : mode, tm, nt_best) + 1) use_dma = true, p.plane = plane16;
-        if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "  lds-dma pipeline: %s (%zu B LDS, %d slots)\n", use_dma ? "yes" : "no", lds_dma, slots);
+        if (opt.tune_print) fprintf(stderr, "  lds-dma pipeline: %s (%zu B LDS, %d slots)\n", use_dma ? "yes" : "no", lds_dma, slots);
     }
     const int kdeep_best = (up && !use_all && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
     size_t lds = (up && !use_all) ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
@@ -1158,7 +1168,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         lds_dma = sizeof(float) * (((size_t)kc * 9 * tn + (size_t)kc * p.plane) + 4 * ((size_t)20 * tn + 2 * (size_t)p.plane) + (size_t)((k_ch + 7) / 8) * 8);
         use_x3 = lds_dma <= 160 * 1024;
         if (!use_x3 && mode == W2E_CONV_DOWN) use_dma = false;  // (DOWN takes the DMA pipeline only for this mode)
-        if (getenv("W2E_TUNE_PRINT")) fprintf(stderr, "  bf16x3: %s (%zu B LDS)\n", use_x3 ? "yes" : "no", lds_dma);
+        if (opt.tune_print) fprintf(stderr, "  bf16x3: %s (%zu B LDS)\n", use_x3 ? "yes" : "no", lds_dma);
     }
     if (use_dma) lds = lds_dma;
     W2E_REQUIRE(lds <= 160 * 1024, "modconv3x3: tile needs %zu B of LDS", lds);
@@ -1172,9 +1182,10 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
+#ifdef W2E_TUNING
     // tuning aid: W2E_TUNE_CLOCK=1 stamps every workgroup and reports the in-kernel shader clock (s_memtime ticks per
     // 100 MHz s_memrealtime tick) of every 64th launch -- the DVFS-limited clock is what an MFMA-bound kernel is priced by
-    static const bool tune_clock = getenv("W2E_TUNE_CLOCK") && atoi(getenv("W2E_TUNE_CLOCK"));
+    const bool tune_clock = opt.tune_clock != 0;
     static unsigned long long* stamp_buf = nullptr;
     static int64_t stamp_cap = 0, stamp_calls = 0;
     bool stamped = false;
@@ -1186,6 +1197,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         }
         if (stamp_buf && hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid, s) == hipSuccess) p.stamps = stamp_buf, stamped = true;
     }
+#endif
     if (p.splits > 1 &&
         hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
@@ -1225,6 +1237,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     }
     W2E_REQUIRE(ok, "modconv3x3: internal: configuration %d not instantiated", best);
     W2E_LAUNCH_CHECK("modconv3x3");
+#ifdef W2E_TUNING
     if (stamped) {
         unsigned long long* hb = (unsigned long long*)malloc(sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid);
         if (hb && hipStreamSynchronize(s) == hipSuccess &&
@@ -1249,6 +1262,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         }
         free(hb);
     }
+#endif
     if (act && p.splits > 1) {  // the activation needs the complete sum: one in-place elementwise pass
         const int rc = w2e_bias_act_fwd(y, bias, noise, noise_w, y, batch, n_ch, (int64_t)h * w, 0.2f, 1.4142135623730951f, stream);
         if (rc != 0) return rc;

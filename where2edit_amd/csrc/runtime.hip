@@ -1,0 +1,96 @@
+// Library-level state of libw2e.so: the thread-local error string and the process-wide options.
+//
+// Options are read from the environment ONCE, when the library is loaded, and afterwards change only through
+// w2e_set_option() -- no entry point calls getenv() on its launch path.  They are the only global mutable state of
+// the library besides the per-device "large dynamic LDS enabled" flags of the kernels (see big_lds_once()).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace w2e {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static Options g_opt;
+
+static int parse_precision(const char* v) { return (v && strcmp(v, "bf16x3") == 0) ? 1 : 0; }
+
+static bool apply(Options& o, const char* name, const char* value) {
+    const int iv = value ? atoi(value) : 0;
+    if (!strcmp(name, "conv_precision")) o.conv_precision = parse_precision(value);
+    else if (!strcmp(name, "deterministic")) o.deterministic = iv != 0;
+    else if (!strcmp(name, "tune_cfg")) {  // "<cfg>[,<splits>[,<mode>]]"; "" or "-1" = off
+        o.tune_cfg = -1, o.tune_cfg_splits = 1, o.tune_cfg_mode = -1;
+        if (value && *value) sscanf(value, "%d,%d,%d", &o.tune_cfg, &o.tune_cfg_splits, &o.tune_cfg_mode);
+    } else if (!strcmp(name, "tune_upall")) o.tune_upall = (value && *value) ? iv : -1;
+    else if (!strcmp(name, "tune_dma")) o.tune_dma = (value && *value) ? iv : -1;
+    else if (!strcmp(name, "tune_print")) o.tune_print = iv;
+    else if (!strcmp(name, "tune_blur")) o.tune_blur = iv;
+    else if (!strcmp(name, "tune_gemm_s")) o.tune_gemm_s = iv;
+    else if (!strcmp(name, "tune_fuse")) o.tune_fuse = (value && *value) ? iv : -1;
+#ifdef W2E_TUNING
+    else if (!strcmp(name, "tune_skip")) o.tune_skip = iv;
+    else if (!strcmp(name, "tune_clock")) o.tune_clock = iv;
+#endif
+    else return false;
+    return true;
+}
+
+static Options from_env() {
+    Options o{};
+    o.tune_cfg = -1, o.tune_cfg_splits = 1, o.tune_cfg_mode = -1, o.tune_upall = -1, o.tune_dma = -1, o.tune_fuse = -1;
+    static const char* const kEnv[][2] = {
+        {"W2E_CONV_PRECISION", "conv_precision"}, {"W2E_DETERMINISTIC", "deterministic"}, {"W2E_TUNE_CFG", "tune_cfg"},
+        {"W2E_TUNE_UPALL", "tune_upall"},         {"W2E_TUNE_DMA", "tune_dma"},           {"W2E_TUNE_PRINT", "tune_print"},
+        {"W2E_TUNE_BLUR", "tune_blur"},           {"W2E_TUNE_GEMM_S", "tune_gemm_s"},     {"W2E_TUNE_FUSE", "tune_fuse"},
+        {"W2E_TUNE_SKIP", "tune_skip"},           {"W2E_TUNE_CLOCK", "tune_clock"}};
+    for (const auto& e : kEnv)
+        if (const char* v = getenv(e[0])) apply(o, e[1], v);
+    return o;
+}
+
+struct OptionsInit {
+    OptionsInit() { g_opt = from_env(); }
+};
+static OptionsInit g_opt_init;  // runs when the shared library is loaded
+
+const Options& options() { return g_opt; }
+
+}  // namespace w2e
+
+extern "C" {
+
+int w2e_version(void) { return W2E_VERSION; }
+const char* w2e_last_error(void) { return w2e::g_err; }
+
+int w2e_set_option(const char* name, const char* value) {
+    W2E_REQUIRE(name != nullptr, "set_option: null name");
+    W2E_REQUIRE(w2e::apply(w2e::g_opt, name, value), "set_option: unknown option '%s'", name);
+    return 0;
+}
+
+int w2e_get_option(const char* name, int* value) {
+    W2E_REQUIRE(name && value, "get_option: null argument");
+    const w2e::Options& o = w2e::g_opt;
+    if (!strcmp(name, "conv_precision")) *value = o.conv_precision;
+    else if (!strcmp(name, "deterministic")) *value = o.deterministic;
+    else if (!strcmp(name, "tune_cfg")) *value = o.tune_cfg;
+    else if (!strcmp(name, "tuning_build")) {
+#ifdef W2E_TUNING
+        *value = 1;
+#else
+        *value = 0;
+#endif
+    } else W2E_REQUIRE(false, "get_option: unknown option '%s'", name);
+    return 0;
+}
+
+}  // extern "C"

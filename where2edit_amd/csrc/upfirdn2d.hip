@@ -428,7 +428,7 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     if (total == 0) return 0;
     W2E_REQUIRE(in_layout == 0 || (in_layout == 1 && up == 1 && down == 1 && kh == 4 && kw == 4 && out_w >= 32),
                 "upfirdn2d: the phase-planar input layout is implemented for the 4x4, up=down=1 tile kernel only");
-    static const int tune = getenv("W2E_TUNE_BLUR") ? atoi(getenv("W2E_TUNE_BLUR")) : 0;
+    const int tune = options().tune_blur;
     UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip, tune, in_layout,
                     act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain};
     hipStream_t s = (hipStream_t)stream;

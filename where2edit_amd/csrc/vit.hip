@@ -450,9 +450,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 using namespace w2e;
 
 // Dynamic LDS above 64 KB has to be enabled per kernel (gfx950 has 160 KB per CU).
-static int set_big_lds(const void* fn, size_t bytes) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
-}
 
 extern "C" int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int n, int k, int lda, int ldb, int ldc,
                            int trans_b, int a_gelu, const float* bias, const float* residual, const float* gelu_grad_aux,
@@ -474,7 +471,7 @@ extern "C" int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int 
     if (ldc == n) {
         // per workgroup: ~0.9 us per 64-deep K-step (32 MFMAs per wave) + ~2 us of prologue/epilogue; a split adds the
         // memset launch and the atomics (64 wave-instructions per workgroup at ~50 ns each).  Units: microseconds.
-        static const int tune_s = getenv("W2E_TUNE_GEMM_S") ? atoi(getenv("W2E_TUNE_GEMM_S")) : 0;
+        const int tune_s = options().tune_gemm_s;
         double best = 0.0;
         for (int sp = 1; sp <= 16; ++sp) {
             const int kp = (int)(ceil_div(ceil_div(k, sp), 2 * GBK) * 2 * GBK);
@@ -494,9 +491,10 @@ extern "C" int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int 
     GemmParams p{a, b, c, m, n, k, lda, ldb, ldc, bias, residual, gelu_grad_aux, k_per};
     dim3 grid((unsigned)ceil_div(n, GBN), (unsigned)ceil_div(m, GBM), (unsigned)splits);
     constexpr size_t lds = sizeof(float4) * 2 * (GBK / 4) * (GPA + GPB);  // two stages, 99 KB
-    static const bool lds_ok = set_big_lds((const void*)gemm_kernel<true, true>, lds) == 0 &&
-                               set_big_lds((const void*)gemm_kernel<true, false>, lds) == 0 &&
-                               set_big_lds((const void*)gemm_kernel<false, false>, lds) == 0;
+    static unsigned done[3] = {0, 0, 0};  // per (kernel, device)
+    const bool lds_ok = big_lds_once((const void*)gemm_kernel<true, true>, &done[0]) &&
+                        big_lds_once((const void*)gemm_kernel<true, false>, &done[1]) &&
+                        big_lds_once((const void*)gemm_kernel<false, false>, &done[2]);
     W2E_REQUIRE(lds_ok, "gemm: cannot enable %zu B of dynamic LDS", lds);
     if (trans_b) {
         if (a_gelu) gemm_kernel<true, true><<<grid, 256, lds, s>>>(p);
@@ -544,9 +542,8 @@ extern "C" int w2e_attn_fwd(const float* qkv, float* out, int batch, int seq, in
     W2E_REQUIRE(seq > 0 && seq <= LMAX && heads > 0 && batch >= 0, "attn_fwd: seq %d (max %d), heads %d", seq, LMAX, heads);
     if (batch == 0) return 0;
     const size_t lds = sizeof(float) * 4 * LMAX * HS;
-    static int configured_fwd = -1;
-    if (configured_fwd != 0) configured_fwd = set_big_lds((const void*)attn_fwd_kernel, lds);
-    W2E_REQUIRE(configured_fwd == 0, "attn_fwd: cannot raise the dynamic LDS limit to %zu B", lds);
+    static unsigned done = 0;
+    W2E_REQUIRE(big_lds_once((const void*)attn_fwd_kernel, &done), "attn_fwd: cannot raise the dynamic LDS limit to %zu B", lds);
     attn_fwd_kernel<<<batch * heads, 256, lds, (hipStream_t)stream>>>(qkv, out, seq, heads);
     W2E_LAUNCH_CHECK("attn_fwd");
     return 0;
@@ -557,9 +554,8 @@ extern "C" int w2e_attn_bwd(const float* qkv, const float* gout, float* gqkv, in
     W2E_REQUIRE(seq > 0 && seq <= LMAX && heads > 0 && batch >= 0, "attn_bwd: seq %d (max %d), heads %d", seq, LMAX, heads);
     if (batch == 0) return 0;
     const size_t lds = sizeof(float) * 6 * LMAX * HS;
-    static int configured = -1;
-    if (configured != 0) configured = set_big_lds((const void*)attn_bwd_kernel, lds);
-    W2E_REQUIRE(configured == 0, "attn_bwd: cannot raise the dynamic LDS limit to %zu B", lds);
+    static unsigned done = 0;
+    W2E_REQUIRE(big_lds_once((const void*)attn_bwd_kernel, &done), "attn_bwd: cannot raise the dynamic LDS limit to %zu B", lds);
     attn_bwd_kernel<<<batch * heads, 256, lds, (hipStream_t)stream>>>(qkv, gout, gqkv, seq, heads);
     W2E_LAUNCH_CHECK("attn_bwd");
     return 0;

@@ -21,9 +21,13 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        # every kernel of libw2e.so launches on the CURRENT device's stream: make the rank's GPU current whatever the
+        # backend and world size (gloo self-tests may map several ranks onto one GPU)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     return rank, world, local
 
 

@@ -23,6 +23,37 @@ from . import functional as K
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 
 
+def invalidate_caches(module):
+    """Drop every derived-weight cache under `module` (packed conv weights, sum_k W^2, scaled EqualLinear / ToRGB weights,
+    the stacked style affines).  The caches are keyed on (data_ptr, Tensor._version): optimizer steps, load_state_dict and
+    any in-place op bump the version and rebuild them by themselves, but writes through `.data` (the reference Ranger's
+    `p.data.copy_`, rosinality's EMA `accumulate`) do NOT -- call this after such writes."""
+    for m in module.modules():
+        for attr in ("_cache_key", "_scaled_key", "_wsc_key", "_style_pack_key"):
+            if hasattr(m, attr):
+                setattr(m, attr, None)
+        if hasattr(m, "_text_cache"):
+            m._text_cache = None
+
+
+def _frozen_weight(mod, what):
+    """The 3x3 / 1x1 conv weights are consumed as packed, detached copies: there is no weight-gradient kernel (the decoder
+    is never optimised on this path, coach.py:174-180).  Refuse, loudly, to run in a mode where autograd would expect one."""
+    if torch.is_grad_enabled() and mod.weight.requires_grad:
+        raise RuntimeError(f"{what}: the conv weight requires grad, but where2edit_amd computes no conv-weight gradients "
+                           "(frozen-decoder path).  Call decoder.requires_grad_(False) (Coach does), or run under "
+                           "torch.no_grad(); modulation / noise / bias / ToRGB parameters may stay trainable.")
+
+
+def freeze_conv_weights(module):
+    """requires_grad_(False) on exactly the parameters this implementation cannot differentiate: the 3x3 (and generic 1x1)
+    ModulatedConv2d weights consumed through the packed-weight kernels.  Everything else stays as it was."""
+    for m in module.modules():
+        if isinstance(m, ModulatedConv2d):
+            m.weight.requires_grad_(False)
+    return module
+
+
 class PixelNorm(nn.Module):
     """model.py:11-17 ([B,512]-sized: stock torch ops)."""
 
@@ -217,6 +248,7 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input, style, input_is_stylespace=False):
         if self.kernel_size not in (1, 3):
             raise NotImplementedError("ModulatedConv2d kernels exist for kernel_size 1 and 3 (the sizes the generator uses)")
+        _frozen_weight(self, "ModulatedConv2d")
         batch, in_channel, height, width = input.shape
         style = self._style(style, batch, input_is_stylespace)
         s2d = style.reshape(batch, in_channel)
@@ -283,6 +315,7 @@ class StyledConv(nn.Module):
             out, style = conv(input, style, input_is_stylespace=input_is_stylespace)
             out = self.noise(out, noise=noise)
             return self.activate(out), style
+        _frozen_weight(conv, "StyledConv")
         style = conv._style(style, batch, input_is_stylespace)
         s2d = style.reshape(batch, conv.in_channel)
         fwd, bwd, wsq = conv._derived()
