@@ -176,7 +176,8 @@ def self_launch(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():  # ONE JSON line on stdout (the contract); anything else rank 0 printed -> stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     raise SystemExit(max(abs(rc) for rc in rcs))
 
