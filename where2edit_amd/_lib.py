@@ -60,6 +60,8 @@ def load():
             fn.restype, fn.argtypes = res, args
         from . import _lib_vit  # noqa: F401  (registers the ViT entry points when present)
         _lib_vit.declare(lib)
+        from . import run_attention as _ra  # the region-attention entry points (include/w2e_attention.h)
+        _ra.declare(lib)
         if lib.w2e_version() != 2:
             raise RuntimeError("libw2e.so version mismatch: rebuild with `python -m where2edit_amd.build --force`")
         _lib = lib
