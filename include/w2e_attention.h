@@ -27,6 +27,13 @@ extern "C" {
 int w2e_cluster_assign(const float* feat, const float* centroids, int32_t* assign, int batch, int channels, int pos_channels,
                        int size, int clusters, void* stream);
 
+/* Lloyd's centroid-update step for the offline clustering (attention/clustering_feature.py:212-235, 373-397):
+ * partial[b,k,d] = sum over the pixels of image b assigned to cluster k of dimension d (d < C: feat[b,d,.]; then the P
+ * x-position and P y-position channels, evaluated as in w2e_cluster_assign), counts[b,k] = number of such pixels.
+ * partial [B,K,C+2P], counts [B,K]; written, not accumulated; the caller sums over b.  K <= 32. */
+int w2e_cluster_accumulate(const float* feat, const int32_t* assign, float* partial, float* counts, int batch, int channels,
+                           int pos_channels, int size, int clusters, void* stream);
+
 #define W2E_ATT_MAX_SOURCES 32
 /* One source = one cached activation and the 1x1 StyledConv(C, 32, 1, C) applied to it with a style given in S-space:
  *   a[b,o,p] = lrelu( d[b,o] * sum_i wscaled[o,i] * s[b,i] * feat[b,i,src(p)] + nw*noise[b,p] + bias[o] ) * sqrt2

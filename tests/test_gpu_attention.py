@@ -174,3 +174,30 @@ def test_region_attention_trainer_step_matches_oracle():
                       "trainable mapper parameters")
     moved = [n for n, p in params.items() if not torch.equal(p.detach(), before[n])]
     assert moved and all(n.startswith("mapper_") for n in moved)
+
+
+def test_gpu_lloyd_matches_cpu_lloyd():
+    """attention/clustering_feature.py:212-235 on the GPU kernels (assignment + fixed-order per-cluster sums on the
+    up-sampled activation in place) against a literal CPU Lloyd on the [N,576] point matrix, same initial centres."""
+    from where2edit_amd import clustering_feature as CF
+    b, c, s, k = 2, 512, 16, 6
+    protos = seeded.tensor("kmeans.protos", (k, c), 1.0)
+    lab = torch.from_numpy(np.random.RandomState(3).randint(0, k, size=(b, s, s)))
+    feat = (protos[lab].permute(0, 3, 1, 2) + 0.3 * seeded.tensor("kmeans.noise", (b, c, s, s))).contiguous()
+    pts = CF.clustering_points(feat.to(DEV))                     # [B,512,32,32]
+    X = CF.points_matrix(pts).cpu()                              # literal [N,576]
+    assert_close(X, CF.points_matrix(torch.nn.functional.interpolate(feat, size=2 * s, mode="bilinear", align_corners=True)), 1e-6)
+    init = X[torch.tensor([5, 300, 700, 1100, 1500, 1900])].clone()
+    cen = init.clone()
+    for _ in range(300):  # the reference's loop
+        ch = torch.argmin(OA.pairwise_distance(X, cen), 1)
+        new = torch.stack([X[ch == i].mean(0) if (ch == i).any() else cen[i] for i in range(k)])
+        shift = torch.sum(torch.sqrt(torch.sum((new - cen) ** 2, 1)))
+        cen = new
+        if shift ** 2 < 1e-4:
+            break
+    assign, centres = CF.lloyd(pts, k, initial_state=init)
+    assert torch.equal(assign.cpu().long().reshape(-1), ch)
+    assert_close(centres, cen, 1e-5, "k-means centres")
+    sums, counts = CF.cluster_sums(pts, assign, k)
+    assert torch.equal(counts.cpu().long(), torch.bincount(ch, minlength=k))

@@ -6,6 +6,12 @@
 
 namespace w2e {
 
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------- cluster assignment
 // One thread per pixel, lanes along x (coalesced channel-plane reads); centroids in LDS as [dim][KP] so that the K
 // distances of one channel come from KP/4 broadcast ds_read_b128.  Distances accumulate in the reference's form
@@ -57,6 +63,47 @@ __global__ __launch_bounds__(256) void cluster_assign_kernel(const float* __rest
     for (int k = 1; k < KP; ++k)
         if (k < K && dist[k] < bd) bd = dist[k], best = k;
     assign[(int64_t)b * S * S + pix] = best;
+}
+
+// ---------------------------------------------------------------------------------------- k-means centroid update
+// Lloyd's update step for the offline clustering (attention/clustering_feature.py:212-235): per image b and feature
+// dimension d (a channel plane, or one of the 2P analytic position channels) the sum of that dimension over the pixels of
+// every cluster.  One workgroup per (d, b); each thread keeps K running sums in registers, then a fixed-order reduction
+// (wave shuffles, 4 wave partials).  partial[b][k][d]; the caller sums over b (deterministic, no atomics).
+template <int KP>
+__global__ __launch_bounds__(256) void cluster_accumulate_kernel(const float* __restrict__ feat, const int32_t* __restrict__ assign,
+                                                                 float* __restrict__ partial, float* __restrict__ counts, int C,
+                                                                 int P, int S, int K) {
+    __shared__ float red[4][KP];
+    const int d = blockIdx.x, b = blockIdx.y, D = C + 2 * P, npix = S * S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+    const int32_t* a = assign + (int64_t)b * npix;
+    const float* f = d < C ? feat + ((int64_t)b * C + d) * npix : nullptr;
+    for (int p = threadIdx.x; p < npix; p += 256) {
+        float v;
+        if (d < C) v = f[p];
+        else if (d < C + P) v = (float)(p % S) * 2.f / (float)(S - 1) - 1.f;
+        else if (d < D) v = (float)(p / S) * 2.f / (float)(S - 1) - 1.f;
+        else v = 1.f;  // d == D: the pixel count
+        const int k = a[p];
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) acc[kk] += (kk == k) ? v : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const float t = wave_sum64(acc[k]);
+        if (lane == 0) red[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const int k = threadIdx.x;
+        const float t = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        if (d < D) partial[((int64_t)b * K + k) * D + d] = t;
+        else counts[(int64_t)b * K + k] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- attention logits
@@ -142,12 +189,6 @@ __global__ void att_finish_kernel(const float* __restrict__ partial, const float
 // ---------------------------------------------------------------------------------------- cluster pooling
 // One workgroup per sample.  Per-cluster sums by a fixed reduction tree (lanes -> wave shuffles -> 4 wave partials in
 // LDS, added in wave order): bit-reproducible.  Then threshold and the separable 5-tap gaussian with reflect padding.
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void cluster_pool_kernel(const float* __restrict__ each, const int32_t* __restrict__ assign,
                                                            float* __restrict__ same, float* __restrict__ means,
                                                            float* __restrict__ counts, float* __restrict__ thr_out,
@@ -236,6 +277,21 @@ extern "C" int w2e_cluster_assign(const float* feat, const float* centroids, int
         cluster_assign_kernel<32><<<grid, 256, lds, s>>>(feat, centroids, assign, channels, pos_channels, size, clusters);
     }
     W2E_LAUNCH_CHECK("cluster_assign");
+    return 0;
+}
+
+extern "C" int w2e_cluster_accumulate(const float* feat, const int32_t* assign, float* partial, float* counts, int batch,
+                                      int channels, int pos_channels, int size, int clusters, void* stream) {
+    W2E_REQUIRE(feat && assign && partial && counts, "cluster_accumulate: null tensor");
+    W2E_REQUIRE(batch >= 0 && channels > 0 && pos_channels >= 0 && size > 1, "cluster_accumulate: bad dims");
+    W2E_REQUIRE(clusters >= 1 && clusters <= 32, "cluster_accumulate: 1 <= clusters <= 32 (got %d)", clusters);
+    if (batch == 0) return 0;
+    dim3 grid((unsigned)(channels + 2 * pos_channels + 1), (unsigned)batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (clusters <= 8) cluster_accumulate_kernel<8><<<grid, 256, 0, s>>>(feat, assign, partial, counts, channels, pos_channels, size, clusters);
+    else if (clusters <= 16) cluster_accumulate_kernel<16><<<grid, 256, 0, s>>>(feat, assign, partial, counts, channels, pos_channels, size, clusters);
+    else cluster_accumulate_kernel<32><<<grid, 256, 0, s>>>(feat, assign, partial, counts, channels, pos_channels, size, clusters);
+    W2E_LAUNCH_CHECK("cluster_accumulate");
     return 0;
 }
 

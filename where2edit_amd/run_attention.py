@@ -42,6 +42,7 @@ class _AttSource(ctypes.Structure):  # w2e_att_source (include/w2e_attention.h)
 PROTOS = {
     "w2e_cluster_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "w2e_cluster_accumulate": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "w2e_attention_logits": (ctypes.c_int, [ctypes.POINTER(_AttSource), ctypes.c_int] + [ctypes.c_void_p] * 9 +
                              [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "w2e_cluster_pool": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p]),
