@@ -216,6 +216,7 @@ def main():
                     help="the roofline's HIP events are recorded on every N-th timed step (166 timed event records per step "
                          "cost the step 5 %%: 159 images/s without them, 150 with them on every step)")
     ap.add_argument("--no-preview", action="store_true", help="skip the extra K steps in the opt-in bf16x3 conv precision (N=1 only)")
+    ap.add_argument("--synthetic-mask", action="store_true", help="workload 3: a seeded U(0,1) mask instead of the region-attention net's")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank; default) or gloo (self-test: the ranks may share a GPU)")
     ap.add_argument("--no-stabilise", action="store_true", help="skip the untimed steady-state loop before the warm-up steps")
@@ -249,9 +250,34 @@ def main():
     coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend, args.workload)
     w = synthetic_latents(coach.net.decoder, args.batch, rank)
     mask = None
-    if args.workload == 3:  # seeded U(0,1) mask at the resolution of layer 13
-        res = 4 * 2 ** ((13 - 1) // 3) if args.size == 1024 else max(4, args.size // 16)
-        mask = torch.rand(args.batch, 1, res, res, generator=torch.Generator().manual_seed(77 + rank)).to(device)
+    if args.workload == 3:
+        if args.size == 1024 and not args.synthetic_mask:
+            # the real mask: the region-attention net's mask branch (run_attention.py:754-884) on the activations of G(w) --
+            # nearest-centroid assignment of the layer-13 features to 20 clusters, the 18 gathered 1x1 StyledConvs + the
+            # 576->1 one + sigmoid, per-cluster pooling, threshold, 5x5 gaussian.  Random-init net and centres (no network).
+            from where2edit_amd.run_attention import FullSpaceMapperFEATClusterLinStyle_Net, cluster_pool
+            torch.manual_seed(1)
+            att_net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
+                                                             clusters=20, cluster_dim=576).to(device).requires_grad_(False)
+            with torch.no_grad():
+                att_net.initial_bias.fill_(1.0)  # (the reference's init of 5 saturates the sigmoid: every cluster passes the threshold)
+            att_text = torch.randn(args.batch, 512, generator=torch.Generator().manual_seed(5 + rank)).to(device) * 0.3
+            const_in = coach.net.decoder.input.input
+
+            def mask(feats):
+                fm = list(feats) + [const_in.repeat(args.batch, 1, 1, 1)]
+                if not hasattr(att_net, "_seeded"):  # centres = 20 pixels of the first batch's features: non-trivial clusters
+                    f = fm[12]
+                    idx = torch.randperm(64 * 64, generator=torch.Generator().manual_seed(3))[:20]
+                    pts = f[0].reshape(512, -1)[:, idx.to(f.device)].t()
+                    ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
+                    att_net.store_clusters(torch.cat([pts, xs.to(f.device)[:, None].repeat(1, 32), ys.to(f.device)[:, None].repeat(1, 32)], 1))
+                att_net._seeded = True
+                each, assign = att_net.attention_map(fm, 64, att_text, 26)
+                return cluster_pool(each, assign, 64, 20)[4]
+        else:  # seeded U(0,1) mask at the resolution of layer 13
+            res = 4 * 2 ** ((13 - 1) // 3) if args.size == 1024 else max(4, args.size // 16)
+            mask = torch.rand(args.batch, 1, res, res, generator=torch.Generator().manual_seed(77 + rank)).to(device)
 
     def barrier():
         if world > 1:
@@ -296,8 +322,9 @@ def main():
         "dtype": args.conv_precision, "data": "synthetic",
         "config": {"workload": (f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
                                 f"LevelsMapper, Ranger, id_lambda=0") if args.workload == 2 else
-                               (f"FFHQ-{args.size} mapper step with the region-attention mask blend at layer 13 (attention_model.py) "
-                                f"+ clip_loss + id_loss (IR-SE50, stock ops), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
+                               (f"FFHQ-{args.size} mapper step with the region-attention mask (cluster-pooled, thresholded, blurred: run_attention.py:754-884"
+                                f"{' -- synthetic U(0,1) mask' if callable(mask) is False else ''}) blended at layer 13 (attention_model.py) "
+                                f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
                    "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
                    "stabilise_steps": stab_steps, "stabilised": stab_ok, "dist_backend": args.dist_backend if world > 1 else None},

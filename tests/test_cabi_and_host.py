@@ -36,8 +36,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_ctypes_prototypes_cover_the_header():
-    from where2edit_amd import _lib, _lib_vit, run_attention
-    assert sorted(list(_lib._PROTOS) + list(_lib_vit.PROTOS) + list(run_attention.PROTOS)) == _declared_symbols()
+    from where2edit_amd import _lib, _lib_vit, irse_hip, run_attention
+    assert sorted(list(_lib._PROTOS) + list(_lib_vit.PROTOS) + list(run_attention.PROTOS) + list(irse_hip.PROTOS)) == _declared_symbols()
 
 
 def test_version_and_argument_errors_do_not_need_a_gpu(lib):

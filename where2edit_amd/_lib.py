@@ -62,6 +62,8 @@ def load():
         _lib_vit.declare(lib)
         from . import run_attention as _ra  # the region-attention entry points (include/w2e_attention.h)
         _ra.declare(lib)
+        from . import irse_hip as _ir  # the IR-SE50 entry points (include/w2e_irse.h)
+        _ir.declare(lib)
         if lib.w2e_version() != 2:
             raise RuntimeError("libw2e.so version mismatch: rebuild with `python -m where2edit_amd.build --force`")
         _lib = lib

@@ -63,7 +63,7 @@ class Coach:
         return Ranger(params, lr=self.opts.learning_rate)
 
     def forward_pair(self, w, mask=None):
-        """coach.py:80-89 (W+ and S-space branches).  With `mask` [B,1,s,s] and opts.attention_layer > 0 (BASELINE
+        """coach.py:80-89 (W+ and S-space branches).  With `mask` ([B,1,s,s], or a callable features -> mask) and opts.attention_layer > 0 (BASELINE
         configs[2]) the edited image is generated the region-attention way (attention/run_attention.py:1104-1126): the
         decoder is attention_model.Generator, the unedited pass also returns its 26 activations, and the edited pass
         blends layer `attention_layer` (and the ToRGB after it) with them under the mask."""
@@ -75,6 +75,8 @@ class Coach:
                 x, _, _, feats = dec([w], input_is_latent=True, randomize_noise=False, truncation=1, return_features=True,
                                      input_is_stylespace=s_space)
             self._x_ready = None
+            if callable(mask):  # the region-attention net's mask branch, fed with the unedited pass's activations
+                mask = mask(feats)  # (run_attention.py:1231-1245: the mask is a function of the cached features)
             if s_space:  # the S-space blend sites of attention_model.py:573-588, 637-660 (run_attention.py:1245)
                 delta = self.net.mapper(w)
                 w_hat = [c + 0.1 * dc for c, dc in zip(w, delta)]

@@ -56,11 +56,13 @@ struct ConvParams {
     unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
     int border_wgs, groups_row, groups_col;  // UP: leading workgroups that compute the last row / column
     int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop, bit2 = stage only the first chunk, bit5 = no UP border
+    const float* slope;  // EPI_PRELU: per-output-channel negative slope (v = v > 0 ? v : slope[o]*v after out_scale and bias)
+    int in_off;          // DOWN: the input origin is shifted by in_off (-1 = a stride-2 convolution with padding 1 of an in_h x in_w image)
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
     unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
 };
 
-enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2 };
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3 };
 
 // Internal variant of W2E_CONV_UP chosen by the host per layer: a workgroup computes ALL FOUR output phases of a
 // (4x smaller) input-pixel tile from one staged patch and all 9 taps -- the NPB accumulator columns of a wave are
@@ -364,8 +366,8 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 
     const int64_t in_plane = (int64_t)p.in_h * p.in_w;
     const int patch = p.ph * p.pw;
-    const int oy0 = (MODE == W2E_CONV_DOWN) ? 2 * r0 : r0 - 1;
-    const int ox0 = (MODE == W2E_CONV_DOWN) ? 2 * c0 : c0 - 1;
+    const int oy0 = (MODE == W2E_CONV_DOWN) ? 2 * r0 + p.in_off : r0 - 1;
+    const int ox0 = (MODE == W2E_CONV_DOWN) ? 2 * c0 + p.in_off : c0 - 1;
 
     // ---- software pipeline (T14 "issue early / write late"): the global loads of chunk k+1 are issued into
     // registers right after chunk k is published to LDS and land while chunk k's MFMAs run; they are
@@ -751,7 +753,15 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         for (int r = 0; r < 16; ++r) {
             const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             os[r] = (o < p.N && p.out_scale) ? p.out_scale[b * p.N + o] : 1.f;
-            bs[r] = (EPI == EPI_ACT && o < p.N && p.bias) ? p.bias[o] : 0.f;
+            bs[r] = ((EPI == EPI_ACT || EPI == EPI_PRELU) && o < p.N && p.bias) ? p.bias[o] : 0.f;
+        }
+        float sl[EPI == EPI_PRELU ? 16 : 1];
+        if (EPI == EPI_PRELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                sl[r] = (o < p.N && p.slope) ? p.slope[o] : 1.f;
+            }
         }
         if (EPI == EPI_DOT) {  // pass 1: loads + reductions only, 8 rows (8*NPB loads in flight per lane) at a time
 #pragma unroll
@@ -799,6 +809,10 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                     if (EPI == EPI_ACT) {
                         v += bs[r] + nz[pb];
                         v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
+                    }
+                    if (EPI == EPI_PRELU) {
+                        v += bs[r];
+                        v = v > 0.f ? v : sl[EPI == EPI_PRELU ? r : 0] * v;
                     }
                     if (W2E_SKIP(p, 1) && v != 123456.789f) continue;  // tuning aid: no stores, arithmetic kept alive
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[pb], soff, 0);
@@ -972,20 +986,25 @@ extern "C" int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, 
     return 0;
 }
 
-extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
-                              float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
-                              const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
-                              void* stream) {
+// The engine behind w2e_modconv3x3 (StyleGAN2 layers) and w2e_conv3x3 (plain convolutions with folded BatchNorm / PReLU:
+// IR-SE50, the e4e encoder).  prelu: epilogue v = prelu(out_scale*acc + bias[o], slope[o]) (SAME / DOWN, no split-K);
+// down_pad: DOWN reads an (2h) x (2w) image with a one-pixel zero border on the top/left (stride 2, padding 1).
+static int conv_impl(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y,
+                     int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise, const float* noise_w,
+                     const float* bias, const float* dot_with, float* dot_out, const float* slope, int prelu, int down_pad,
+                     void* stream) {
     W2E_REQUIRE(mode >= 0 && mode <= 2, "modconv3x3: bad mode %d", mode);
     W2E_REQUIRE(x && wp && y, "modconv3x3: null tensor");
     W2E_REQUIRE(batch >= 0 && k_ch > 0 && n_ch > 0 && h > 0 && w > 0, "modconv3x3: bad dims");
     W2E_REQUIRE(!(act && mode != W2E_CONV_SAME), "modconv3x3: fused activation only in SAME mode");
+    W2E_REQUIRE(!(prelu && (act || dot_with || mode == W2E_CONV_UP)), "conv3x3: the bias/PReLU epilogue is for SAME and DOWN, alone");
+    W2E_REQUIRE(!(down_pad && mode != W2E_CONV_DOWN), "conv3x3: down_pad is a DOWN-mode option");
     W2E_REQUIRE(!(dot_with && (act || mode == W2E_CONV_UP)), "modconv3x3: dot epilogue only without act, not in UP mode");
     W2E_REQUIRE((dot_with == nullptr) == (dot_out == nullptr), "modconv3x3: dot_with and dot_out go together");
     W2E_REQUIRE(!noise || noise_w, "modconv3x3: noise without noise_w");
     if (batch == 0) return 0;
     {   // the kernel addresses one image's input with 32-bit byte offsets (buffer loads)
-        const int64_t ih = mode == W2E_CONV_DOWN ? 2 * (int64_t)h + 1 : h, iw = mode == W2E_CONV_DOWN ? 2 * (int64_t)w + 1 : w;
+        const int64_t ih = mode == W2E_CONV_DOWN ? 2 * (int64_t)h + 1 - down_pad : h, iw = mode == W2E_CONV_DOWN ? 2 * (int64_t)w + 1 - down_pad : w;
         W2E_REQUIRE((int64_t)k_ch * ih * iw * 4 < ((int64_t)1 << 32), "modconv3x3: one image of the input exceeds 4 GB");
         const int64_t oplane = mode == W2E_CONV_UP ? 4 * ((int64_t)h + 1) * ((w + 4) & ~3) : (int64_t)h * w;
         W2E_REQUIRE((int64_t)n_ch * oplane * 4 < ((int64_t)1 << 32) - 16 * oplane, "modconv3x3: one image of the output exceeds 4 GB");
@@ -998,7 +1017,8 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     p.batch = batch, p.K = k_ch, p.N = n_ch, p.H = h, p.W = w;
     if (mode == W2E_CONV_SAME) p.in_h = h, p.in_w = w, p.out_h = h, p.out_w = w;
     else if (mode == W2E_CONV_UP) p.in_h = h, p.in_w = w, p.out_h = 2 * h + 1, p.out_w = 2 * w + 1;
-    else p.in_h = 2 * h + 1, p.in_w = 2 * w + 1, p.out_h = h, p.out_w = w;
+    else p.in_h = 2 * h + 1 - down_pad, p.in_w = 2 * w + 1 - down_pad, p.out_h = h, p.out_w = w, p.in_off = down_pad ? -1 : 0;
+    p.slope = slope;
 
     // ---- pick the tile configuration with a small cost model.  Unit = MFMA cycles on one SIMD.  A CU works
     // through ceil(wgs/256) workgroups (two resident 256-thread workgroups share its matrix pipes, so they
@@ -1095,7 +1115,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     }
     // conv_precision = bf16x3 (option; opt-in, default = exact fp32 MFMA): the SAME, all-phase UP and DOWN tiles
     // of the DMA pipeline compute each fp32 product as three bf16 products (see DMA == 2 in the kernel)
-    const int tune_x3 = opt.conv_precision;
+    const int tune_x3 = prelu ? 0 : opt.conv_precision;  // (the bias/PReLU epilogue is instantiated for the fp32 register pipeline)
     // DOWN in that mode: the 128x256 tile (9) is the one whose stride-2 patch fits beside the bf16 operand images in LDS (156 KB)
     if (tune_x3 == 1 && mode == W2E_CONV_DOWN && (int64_t)h * w >= 4096 && n_ch >= 128 && best >= 0) best = 9, best_splits = 1;  // (N = 64 fills half the tile: slower than fp32)
 #ifdef W2E_TUNING
@@ -1105,7 +1125,7 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
         if (fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
-    if (opt.deterministic) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
+    if (opt.deterministic || prelu) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
@@ -1129,8 +1149,8 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
     const int tune_dma = opt.tune_dma;
     bool use_dma = false;
     size_t lds_dma = 0;
-    const bool dma_auto = use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
-    if ((tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
+    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
+    if (!prelu && (tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
         const int slots = (int)ceil_div(4 * plane16, nt_best);
@@ -1224,6 +1244,9 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
             if (dot_with) ok = launch_mode_dma<W2E_CONV_DOWN, EPI_DOT, 8>(best, p, (int)grid, lds, s);
             else ok = launch_mode_dma<W2E_CONV_DOWN, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
         }
+    } else if (prelu) {
+        if (mode == W2E_CONV_SAME) ok = launch_mode<W2E_CONV_SAME, EPI_PRELU, 8>(best, p, (int)grid, lds, s);
+        else ok = launch_mode<W2E_CONV_DOWN, EPI_PRELU, 8>(best, p, (int)grid, lds, s);
     } else if (mode == W2E_CONV_SAME) {
         if (act && p.splits == 1) ok = launch_mode<W2E_CONV_SAME, EPI_ACT, 8>(best, p, (int)grid, lds, s);
         else if (dot_with) ok = launch_mode<W2E_CONV_SAME, EPI_DOT, 8>(best, p, (int)grid, lds, s);
@@ -1268,4 +1291,21 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
         if (rc != 0) return rc;
     }
     return 0;
+}
+
+extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
+                              float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
+                              const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
+                              void* stream) {
+    return conv_impl(mode, x, wp, in_scale, out_scale, y, batch, k_ch, n_ch, h, w, act, noise, noise_w, bias, dot_with, dot_out,
+                     nullptr, 0, 0, stream);
+}
+
+extern "C" int w2e_conv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y,
+                           int batch, int k_ch, int n_ch, int h, int w, int down_pad, const float* bias, const float* slope,
+                           void* stream) {
+    const int prelu = (bias || slope) ? 1 : 0;
+    W2E_REQUIRE(!(prelu && mode == W2E_CONV_UP), "conv3x3: no bias / PReLU epilogue in UP mode");
+    return conv_impl(mode, x, wp, in_scale, out_scale, y, batch, k_ch, n_ch, h, w, 0, nullptr, nullptr, bias, nullptr, nullptr,
+                     slope, prelu, down_pad, stream);
 }

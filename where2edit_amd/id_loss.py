@@ -1,8 +1,10 @@
 """criteria/id_loss.py + models/facial_recognition surface: `IDLoss(opts)(y_hat, y) -> (loss, 0)` on the IR-SE50
 ArcFace backbone, with the reference's module tree so `model_ir_se50.pth` loads unchanged.
 
-SURVEY 8(a) A9 / 8(f) N1: this network is on the measured path of config 3 only and is NOT a hand-kernel target of
-the north_star; it runs on stock PyTorch-ROCm ops (MIOpen convolutions) here.  Native kernels for it are "next"."""
+SURVEY 8(a) A9 / 8(f) N1: on the GPU, in eval mode with frozen weights (the only way the reference uses it), the
+backbone runs on the hand-written kernels of irse_hip.py / include/w2e_irse.h: the 3x3 convolutions on the fp32-MFMA
+engine of the StyleGAN2 layers with BatchNorm folded and PReLU fused, the SE block on its own kernels.  The module tree
+below is the reference's (state_dict keys) and doubles as the CPU / train-mode execution on stock ops."""
 from collections import namedtuple
 
 import torch
@@ -92,7 +94,21 @@ class Backbone(Module):
                                        BatchNorm1d(512, affine=affine))
         self.body = Sequential(*[unit(b.in_channel, b.depth, b.stride) for blk in get_blocks(num_layers) for b in blk])
 
-    def forward(self, x):
+    def forward(self, x, n_grad=None):
+        """GPU + eval mode + frozen weights (the way criteria/id_loss.py uses it): the hand-written kernels
+        (irse_hip.backbone_forward).  Otherwise -- CPU tensors, train mode, trainable weights -- the stock module tree."""
+        if x.is_cuda and not self.training and x.dtype == torch.float32 and not any(p.requires_grad for p in self.parameters()):
+            from . import irse_hip
+            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            if getattr(self, "_plan_key", None) != key:
+                self._plan = irse_hip.BackbonePlan(self)
+                self._plan_key = key
+            return irse_hip.backbone_forward(self._plan, x, n_grad)
+        if x.is_cuda and not getattr(self, "_warned_stock", False):
+            import warnings
+            warnings.warn("IR-SE50 Backbone is running on stock PyTorch ops (train mode or trainable weights): the HIP path needs "
+                          ".eval() and requires_grad_(False)")
+            self._warned_stock = True
         return l2_norm(self.output_layer(self.body(self.input_layer(x))))
 
 
@@ -123,7 +139,16 @@ class IDLoss(nn.Module):
         return self.facenet(self.face_pool(x))
 
     def forward(self, y_hat, y):
-        y_feats = self.extract_feats(y).detach()
-        y_hat_feats = self.extract_feats(y_hat)
+        if y_hat.is_cuda and y_hat.shape == y.shape and y_hat.shape[2] == y_hat.shape[3] and y_hat.shape[2] % 256 == 0 \
+                and not self.facenet.training:
+            # one pass over [y_hat; y]: twice the rows per launch for the launch-bound 14^2 / 7^2 stages; only the y_hat half
+            # takes part in the backward (y's features are detached in the reference, id_loss.py:33)
+            from . import functional as K
+            n = y_hat.shape[0]
+            feats = self.facenet(K.id_preprocess(torch.cat([y_hat, y.detach()])), n_grad=n)
+            y_hat_feats, y_feats = feats[:n], feats[n:].detach()
+        else:
+            y_feats = self.extract_feats(y).detach()
+            y_hat_feats = self.extract_feats(y_hat)
         loss = (1 - (y_hat_feats * y_feats).sum(1)).mean()  # mean_i (1 - <f(y_hat_i), f(y_i)>)  (id_loss.py:34-40)
         return loss, 0

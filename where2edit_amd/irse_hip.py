@@ -1,0 +1,267 @@
+"""The IR-SE50 ArcFace body (models/facial_recognition/model_irse.py:9-48, helpers.py:56-119) on the hand-written
+kernels (include/w2e_irse.h): every 3x3 / shortcut convolution runs on the fp32-MFMA engine of the StyleGAN2 layers
+(w2e_conv3x3) with eval-mode BatchNorm folded into its scales and bias and PReLU in its epilogue; the SE block is a
+one-wave-per-plane pooling kernel, a [B,C]-sized MLP on rocBLAS, and a gate-and-add kernel.
+
+Eval mode only (criteria/id_loss.py:14 calls facenet.eval()) and frozen weights: forward + INPUT gradients, which is what
+the identity loss needs (the gradient flows back to the generated image).  One autograd node per bottleneck unit."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import functional as K
+from ._lib import call, ptr, stream_ptr
+
+_I = __import__("ctypes").c_int
+_P = __import__("ctypes").c_void_p
+_L = __import__("ctypes").c_int64
+PROTOS = {
+    "w2e_conv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "w2e_affine_act_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _P]),
+    "w2e_affine_act_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "w2e_channel_sums": (_I, [_P, _P, _P, _I, _I, _L, _P]),
+    "w2e_se_apply_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "w2e_se_apply_bwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
+    "w2e_shortcut_add_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+
+def declare(lib):
+    for name, (res, args) in PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+
+
+# ---------------------------------------------------------------------------------------------- raw kernel calls
+def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None):
+    """w2e_conv3x3.  h,w: input size for SAME / UP, output size for DOWN.  in_scale [B,K] / out_scale [B,N] / bias, slope [N]."""
+    b, k = x.shape[0], x.shape[1]
+    if mode == K.MODE_UP:
+        y = torch.empty((b, n_out, 2, 2, h + 1, (w + 4) & ~3), device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
+    call("w2e_conv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n_out, h, w, down_pad, ptr(bias), ptr(slope),
+         stream_ptr())
+    return y
+
+
+def affine_act(x, a=None, b=None, slope=None):
+    y = torch.empty_like(x)
+    call("w2e_affine_act_fwd", ptr(x), ptr(a), ptr(b), ptr(slope), ptr(y), x.shape[0], x.shape[1], x.shape[2] * x.shape[3], stream_ptr())
+    return y
+
+
+def affine_act_bwd(gy, y, a, slope, batch, channels, height, width, planar=False):
+    gx = torch.empty((batch, channels, height, width), device=gy.device, dtype=torch.float32)
+    call("w2e_affine_act_bwd", ptr(gy), ptr(y), ptr(a), ptr(slope), ptr(gx), batch, channels, height, width, int(planar), stream_ptr())
+    return gx
+
+
+def channel_sums(x, y=None):
+    b, c = x.shape[0], x.shape[1]
+    out = torch.empty((b, c), device=x.device, dtype=torch.float32)
+    call("w2e_channel_sums", ptr(x), ptr(y), ptr(out), b, c, x.shape[2] * x.shape[3], stream_ptr())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- folded parameters
+def _bn_affine(bn):
+    a = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    return a.contiguous(), (bn.bias.detach() - bn.running_mean * a).contiguous()
+
+
+class UnitPlan:
+    """Folded, packed, frozen parameters of one bottleneck_IR_SE unit (helpers.py:97-119)."""
+
+    def __init__(self, unit, in_channel, depth, stride):
+        res = unit.res_layer
+        self.cin, self.depth, self.stride = in_channel, depth, stride
+        with torch.no_grad():
+            self.a1, self.b1 = _bn_affine(res[0])
+            w1, w2 = res[1].weight.detach().float(), res[3].weight.detach().float()
+            self.w1f = K.conv_pack(w1, 1.0, transpose=False, flip=False)
+            self.w1b = K.conv_pack(w1, 1.0, transpose=True, flip=True)
+            self.slope = res[2].weight.detach().float().contiguous()
+            self.fused_prelu = bool((self.slope > 0).all().item())  # backward recovers the PReLU branch from sign(output)
+            self.w2f = K.conv_pack(w2, 1.0, transpose=False, flip=False)
+            self.w2b = K.conv_pack(w2, 1.0, transpose=True, flip=(stride == 1))
+            self.a2, self.b2 = _bn_affine(res[4])
+            se = res[5]
+            self.fc1 = se.fc1.weight.detach().float().reshape(se.fc1.weight.shape[0], -1).contiguous()
+            self.fc2 = se.fc2.weight.detach().float().reshape(se.fc2.weight.shape[0], -1).contiguous()
+            self.conv_shortcut = in_channel != depth
+            if self.conv_shortcut:  # Conv2d(in, depth, 1, stride) + BN: the centre tap of a 3x3 (helpers.py:103-106)
+                ws = unit.shortcut_layer[0].weight.detach().float()
+                w9 = torch.zeros(depth, in_channel, 3, 3, device=ws.device)
+                w9[:, :, 1, 1] = ws[:, :, 0, 0]
+                self.wsf = K.conv_pack(w9, 1.0, transpose=False, flip=False)
+                self.wsb = K.conv_pack(w9, 1.0, transpose=True, flip=(stride == 1))
+                self.a_s, self.b_s = _bn_affine(unit.shortcut_layer[1])
+        if not self.fused_prelu:
+            raise RuntimeError("IR-SE50 on the HIP kernels needs positive PReLU slopes (the backward reads the branch from the sign "
+                               "of the output); this checkpoint has a non-positive one")
+
+    def gate(self, pooled):
+        return torch.sigmoid(torch.relu(pooled @ self.fc1.t()) @ self.fc2.t())  # [B,C]-sized (helpers.py:66-71)
+
+
+_REP = {}
+
+
+def _rep(v, batch):
+    """[C] -> [batch, C] (the conv engine takes per-sample scales); cached: the vectors are frozen parameters."""
+    key = (v.data_ptr(), v._version, batch)
+    hit = _REP.get(key)
+    if hit is None or hit[0] is not v:
+        if len(_REP) > 4096:
+            _REP.clear()
+        hit = (v, v.unsqueeze(0).expand(batch, -1).contiguous())
+        _REP[key] = hit
+    return hit[1]
+
+
+class _IRUnit(torch.autograd.Function):
+    """One bottleneck_IR_SE unit.  `n_grad`: only the first n_grad samples of the batch take part in the backward (the id
+    loss embeds [generated; original] in one batch and differentiates the generated half only, id_loss.py:30-33)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, n_grad):
+        x = x if x.is_contiguous() else x.contiguous()
+        b, cin, h, w = x.shape
+        p = plan
+        s = p.stride
+        oh, ow = h // s, w // s
+        t0 = affine_act(x, p.a1, p.b1)                                                   # BN1 (helpers.py:111)
+        t1 = conv3x3(t0, p.w1f, p.depth, h, w, slope=p.slope)                            # conv + PReLU (:112-113)
+        a2 = _rep(p.a2, b)
+        if s == 1:
+            t2 = conv3x3(t1, p.w2f, p.depth, h, w, out_scale=a2, bias=p.b2)              # conv + BN2 (:114-115)
+        else:
+            t2 = conv3x3(t1, p.w2f, p.depth, oh, ow, mode=K.MODE_DOWN, down_pad=1, out_scale=a2, bias=p.b2)
+        gate = p.gate(channel_sums(t2) / float(oh * ow))                                 # SE (:56-72)
+        out = torch.empty_like(t2)
+        if p.conv_shortcut:
+            a_s = _rep(p.a_s, b)
+            if s == 1:
+                sc = conv3x3(x, p.wsf, p.depth, h, w, out_scale=a_s, bias=p.b_s)
+            else:
+                sc = conv3x3(x, p.wsf, p.depth, oh, ow, mode=K.MODE_DOWN, down_pad=1, out_scale=a_s, bias=p.b_s)
+            call("w2e_se_apply_fwd", ptr(t2), ptr(gate), ptr(sc), 0, ptr(out), b, p.depth, oh, ow, stream_ptr())
+        else:  # MaxPool2d(1, stride): the strided samples of x (:100-101)
+            call("w2e_se_apply_fwd", ptr(t2), ptr(gate), ptr(x), s, ptr(out), b, p.depth, oh, ow, stream_ptr())
+        ctx.plan, ctx.geom = plan, (n_grad if n_grad is not None else b, cin, h, w, oh, ow)
+        ctx.save_for_backward(t1, t2, gate)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        t1, t2, gate = ctx.saved_tensors
+        p = ctx.plan
+        n, cin, h, w, oh, ow = ctx.geom
+        s = p.stride
+        full = gout.shape[0]
+        gout = (gout if gout.is_contiguous() else gout.contiguous())[:n]
+        t1, t2, gate = t1[:n], t2[:n], gate[:n]
+        # SE backward: d gate = sum_p gout*t2; through sigmoid / fc2 / relu / fc1 on [n,C] tensors; back to the mean
+        dgate = channel_sums(gout, t2)
+        with torch.enable_grad():
+            pooled = (channel_sums(t2) / float(oh * ow)).requires_grad_(True)
+            g2 = p.gate(pooled)
+            (gpool,) = torch.autograd.grad(g2, pooled, dgate)
+        gpool = (gpool / float(oh * ow)).contiguous()
+        g_t2 = torch.empty_like(gout)
+        call("w2e_se_apply_bwd", ptr(gout), ptr(gate.contiguous()), ptr(gpool), ptr(g_t2), n, p.depth, oh * ow, stream_ptr())
+        a2 = _rep(p.a2, n)
+        if s == 1:
+            g_t1 = conv3x3(g_t2, p.w2b, p.depth, h, w, in_scale=a2)
+            g_c1 = affine_act_bwd(g_t1, t1, None, p.slope, n, p.depth, h, w)
+        else:  # adjoint of the padded stride-2 conv: UP, then the (+1,+1) crop folded into the PReLU backward
+            tt = conv3x3(g_t2, p.w2b, p.depth, oh, ow, mode=K.MODE_UP, in_scale=a2)
+            g_c1 = affine_act_bwd(tt, t1, None, p.slope, n, p.depth, h, w, planar=True)
+        gx = conv3x3(g_c1, p.w1b, cin, h, w, out_scale=_rep(p.a1, n))
+        if p.conv_shortcut:
+            a_s = _rep(p.a_s, n)
+            if s == 1:
+                gs = conv3x3(gout, p.wsb, cin, h, w, in_scale=a_s)
+                call("w2e_shortcut_add_bwd", ptr(gx), ptr(gs), n, cin, h, w, 1, 0, stream_ptr())
+            else:
+                ts = conv3x3(gout, p.wsb, cin, oh, ow, mode=K.MODE_UP, in_scale=a_s)
+                call("w2e_shortcut_add_bwd", ptr(gx), ptr(ts), n, cin, h, w, 1, 1, stream_ptr())
+        else:
+            call("w2e_shortcut_add_bwd", ptr(gx), ptr(gout), n, cin, oh, ow, s, 0, stream_ptr())
+        if n < full:  # the rest of the batch takes no gradient
+            gx = torch.cat([gx, torch.zeros((full - n, cin, h, w), device=gx.device, dtype=torch.float32)])
+        return gx, None, None
+
+
+class _InputLayer(torch.autograd.Function):
+    """Conv2d(3,64,3,1,1) -> BatchNorm2d -> PReLU (model_irse.py:20-22) as one conv launch."""
+
+    @staticmethod
+    def forward(ctx, x, plan, n_grad):
+        x = x if x.is_contiguous() else x.contiguous()
+        b, _, h, w = x.shape
+        y = conv3x3(x, plan["wf"], 64, h, w, out_scale=_rep(plan["a"], b), bias=plan["b"], slope=plan["slope"])
+        ctx.plan, ctx.n = plan, (n_grad if n_grad is not None else b)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        plan, n = ctx.plan, ctx.n
+        full, _, h, w = y.shape
+        g = affine_act_bwd((gy if gy.is_contiguous() else gy.contiguous())[:n], y[:n], plan["a"], plan["slope"], n, 64, h, w)
+        gx = conv3x3(g, plan["wb"], 3, h, w)
+        if n < full:
+            gx = torch.cat([gx, torch.zeros((full - n, 3, h, w), device=gx.device, dtype=torch.float32)])
+        return gx, None, None
+
+
+class BackbonePlan:
+    """Everything `Backbone(112, 50, 'ir_se')` needs on the device, folded and packed once (the weights are frozen)."""
+
+    def __init__(self, backbone):
+        from .id_loss import get_blocks
+        il, ol = backbone.input_layer, backbone.output_layer
+        with torch.no_grad():
+            a, b = _bn_affine(il[1])
+            w0 = il[0].weight.detach().float()
+            slope = il[2].weight.detach().float().contiguous()
+            if not bool((slope > 0).all().item()):
+                raise RuntimeError("IR-SE50 on the HIP kernels needs positive PReLU slopes")
+            self.input = {"wf": K.conv_pack(w0, 1.0, False, False), "wb": K.conv_pack(w0, 1.0, True, True), "a": a, "b": b, "slope": slope}
+            specs = [blk for stage in get_blocks(50 if len(backbone.body) == 24 else (100 if len(backbone.body) == 49 else 152)) for blk in stage]
+            self.units = [UnitPlan(u, s.in_channel, s.depth, s.stride) for u, s in zip(backbone.body, specs)]
+            self.out_a, self.out_b = _bn_affine(ol[0])
+            bn1 = ol[4]
+            a1 = torch.rsqrt(bn1.running_var + bn1.eps) * (bn1.weight.detach() if bn1.affine else 1.0)
+            b1 = (bn1.bias.detach() if bn1.affine else 0.0) - bn1.running_mean * a1
+            # Linear(25088,512) then BatchNorm1d: fold the BN into the weight rows and the bias (model_irse.py:24-28)
+            self.fc_w = (ol[3].weight.detach().float() * a1[:, None]).contiguous()
+            self.fc_b = (ol[3].bias.detach().float() * a1 + b1).contiguous()
+
+
+class _OutputBN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.save_for_backward(a)
+        return affine_act(x if x.is_contiguous() else x.contiguous(), a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (a,) = ctx.saved_tensors
+        n, c, h, w = gy.shape
+        return affine_act_bwd(gy if gy.is_contiguous() else gy.contiguous(), None, a, None, n, c, h, w), None, None
+
+
+def backbone_forward(plan, x, n_grad=None):
+    """Backbone.forward (model_irse.py:44-48): [B,3,112,112] -> L2-normalised [B,512]."""
+    y = _InputLayer.apply(x, plan.input, n_grad)
+    for u in plan.units:
+        y = _IRUnit.apply(y, u, n_grad)
+    y = _OutputBN.apply(y, plan.out_a, plan.out_b)                # BatchNorm2d(512); Dropout is the identity in eval
+    y = torch.nn.functional.linear(y.flatten(1), plan.fc_w, plan.fc_b)  # [B,25088]x[25088,512] on rocBLAS (+ folded BatchNorm1d)
+    return y / torch.norm(y, 2, 1, True)
