@@ -101,3 +101,95 @@ def test_id_loss_on_hip_matches_oracle_with_gradient():
         (go,) = torch.autograd.grad(lo, yo)
         assert zero == 0 and abs(float(loss) - float(lo)) <= 1e-4 * max(abs(float(lo)), 1e-3)
         assert_grad_close(g, go, f"d id_loss / d y_hat at {size}")
+
+
+def test_e4e_encoder_on_hip_matches_reference_fixture():
+    """N3: Encoder4Editing / GradualStyleEncoder (models/encoders/psp_encoders.py:58-200) with the IR-SE50 body, the
+    map2style stride-2 stacks and the lateral 1x1 convolutions on the conv engine, against the reference's outputs."""
+    import make_golden_e4e as ME
+    from where2edit_amd.psp_encoders import Encoder4Editing, GradualStyleEncoder
+    g = golden("e4e")
+    x = seeded.tensor("e4e.x", (1, 3, 256, 256), 0.5).to(DEV)
+    opts = types.SimpleNamespace(stylegan_size=1024)
+    for name, cls in (("e4e", Encoder4Editing), ("gse", GradualStyleEncoder)):
+        net = cls(50, "ir_se", opts).eval()
+        net.load_state_dict(ME.encoder_state_dict(net.state_dict()), strict=True)
+        net = net.to(DEV).requires_grad_(False)
+        with torch.no_grad():
+            w = net(x)
+            assert hasattr(net, "_plan") and hasattr(net.styles[0], "_pack"), "the HIP path did not run"
+            assert_close(w, g[name + ".w"], 1e-4, name + " W+ codes")
+            if name == "e4e":
+                c1, c2, c3 = net._taps(x)
+                for t, key in ((c1, "c1"), (c2, "c2"), (c3, "c3")):
+                    assert_close(t[:, ::8, ::4, ::4], g[f"e4e.{key}_strided"], 1e-4, key)
+            w2 = net(torch.cat([x, x.flip(3)]))  # batch 2
+            assert_close(w2[:1], g[name + ".w"], 1e-4, name + " batch-2, sample 0")
+
+
+def test_config5_invert_and_edit_pipeline_matches_oracle():
+    """BASELINE configs[4] end to end for one image: e4e -> S codes -> features -> region-attention net -> masked 1024^2
+    generator (show_demo/try_demo.py:93-157), every stage against the oracle composition."""
+    import make_golden_attention as MA
+    import make_golden_e4e as ME
+    from make_golden import CLIP_TINY as c
+    from oracle import attention_net as OA
+    from oracle import clip_model as OC
+    from oracle import e4e as OE
+    from oracle import ops as OO
+    from oracle import stylegan2 as OG
+    from where2edit_amd.attention_model import Generator
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.demo_pipeline import gaussian_blur5, invert_and_edit
+    from where2edit_amd.psp_encoders import Encoder4Editing
+    from where2edit_amd.run_attention import FullSpaceMapperFEATClusterLinStyle_Net
+    size, k, att = 1024, 20, 13
+    opts = types.SimpleNamespace(stylegan_size=size)
+    e4e = Encoder4Editing(50, "ir_se", opts).eval()
+    esd = ME.encoder_state_dict(e4e.state_dict())
+    e4e.load_state_dict(esd, strict=True)
+    gsd = seeded.generator_state_dict(size)
+    g = Generator(size, 512, 8)
+    g.load_state_dict(gsd, strict=True)
+    clip = CLIP(embed_dim=c["embed_dim"], vision_layers=c["vision_layers"], vision_width=c["vision_width"],
+                context_length=c["context_length"], vocab_size=c["vocab_size"], transformer_width=c["text_width"],
+                transformer_heads=1, transformer_layers=c["text_layers"])
+    csd = seeded.clip_state_dict(**c)
+    clip.load_state_dict(csd, strict=True)
+    edim = c["embed_dim"]
+    net = FullSpaceMapperFEATClusterLinStyle_Net(18, edim + 512, edim, attention_layer=att, channel_multiplier=2, cluster_layer=att,
+                                                 clusters=k, cluster_dim=576)
+    msd = MA.net_state_dict(net)
+    msd["initial_bias"] = torch.tensor([0.0])
+    img = seeded.tensor("cfg5.img", (1, 3, 256, 256), 0.5)
+    text, att_text = seeded.tensor("cfg5.text", (1, edim), 0.3), seeded.tensor("cfg5.att", (1, edim), 0.3)
+    # oracle, stage by stage
+    with torch.no_grad():
+        w_o = OE.encoder4editing(esd, img)
+        _, _, codes_o = OG.generator_forward(gsd, [w_o], size=size, input_is_latent=True, randomize_noise=False, return_latents=True)
+        img_o, _, _, feats_o = OG.generator_forward(gsd, [codes_o], size=size, input_is_stylespace=True, randomize_noise=False, return_features=True)
+        feats_o = list(feats_o) + [gsd["input.input"]]
+        # centres = 20 pixels of the layer-13 activation (+ their positions): a non-trivial, well-separated assignment
+        f13 = feats_o[att - 1]
+        idx = torch.randperm(64 * 64, generator=torch.Generator().manual_seed(3))[:k]
+        ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
+        msd["initial_state"] = torch.cat([f13[0].reshape(512, -1)[:, idx].t(), xs[:, None].repeat(1, 32), ys[:, None].repeat(1, 32)], 1)
+        x = [torch.cat([text.unsqueeze(1), s[:, :, :, 0, 0]], -1) for s in codes_o]
+        new_o, mask_o, _, extra = OA.forward(msd, x, feats_o, 64, attention_text=att_text, attention_layer=att, cluster_layer=att, clusters=k,
+                                             latent_dim=edim)
+        mask_o = OA.gaussian_blur5(torch.where(mask_o < 0.8, torch.zeros_like(mask_o), mask_o))
+        gen_o, _, _, _ = OG.generator_forward(gsd, [new_o], size=size, input_is_stylespace=True, randomize_noise=False, return_features=True,
+                                              attention_layer=att, attention_map=mask_o, feature_map=feats_o)
+        fo = OC.encode_image(csd, OO.clip_preprocess(gen_o, size))
+    net.load_state_dict(msd, strict=True)
+    out = invert_and_edit(img.to(DEV), e4e.to(DEV).requires_grad_(False), g.to(DEV).requires_grad_(False),
+                          CLIPLoss(opts, model=clip).to(DEV), net.to(DEV).requires_grad_(False), text.to(DEV), att_text.to(DEV),
+                          attention_layer=att)
+    assert_close(out["latents"], w_o, 1e-4, "e4e W+")
+    assert_close(out["img_orig"], img_o, 1e-4, "img_orig")
+    assert 0.02 < float((mask_o > 0).float().mean()) < 0.98, "degenerate mask: the test would not exercise the blend"
+    assert_close(out["mask"], mask_o, 1e-4, "mask")
+    assert_close(out["img_gen"], gen_o, 1e-4, "edited image")
+    assert_close(out["features_gen"], fo, 1e-3, "CLIP features of the edit")
+    assert_close(gaussian_blur5(out["mask"]), OA.gaussian_blur5(mask_o), 1e-5, "blur")

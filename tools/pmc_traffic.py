@@ -2,7 +2,8 @@
 """Turn two rocprofv3 PMC passes of bench.py (--pmc FETCH_SIZE and --pmc WRITE_SIZE, each with --kernel-trace only)
 into profiles/<tag>_pmc_hbm_traffic.txt and profiles/traffic.json.
 
-    tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag>
+    tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <tag> [out_dir]
+(out_dir defaults to profiles/; on the GPU box pass gpurun_out/... and copy the two files into profiles/ afterwards)
 """
 import collections
 import csv
@@ -44,10 +45,11 @@ def main():
             continue
         lines.append(f"{k}, {n}, {fk:.0f}, {wk:.0f}, {(2 * fk + wk) / 1024:.1f}, {(fk + wk) / 1024:.1f}")
         out[k] = (2 * fk + wk) * 1024
-    txt = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.txt")
+    out_dir = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles")
+    txt = os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.txt")
     open(txt, "w").write("\n".join(lines) + "\n")
-    json.dump({"source": os.path.relpath(txt, ROOT), "modconv_hbm_bytes_per_launch": out["w2e::modconv_kernel<*>"]},
-              open(os.path.join(ROOT, "profiles", "traffic.json"), "w"))
+    json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.txt", "modconv_hbm_bytes_per_launch": out["w2e::modconv_kernel<*>"]},
+              open(os.path.join(out_dir, "traffic.json"), "w"))
     print("\n".join(lines))
 
 

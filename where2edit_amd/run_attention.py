@@ -224,7 +224,9 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
         return each, assign
 
     # ---- the style branch (:806-822) ----------------------------------------------------------------------------------
-    def new_styles(self, x, x_text):
+    def new_styles(self, x, x_text, strength_alpha=0.1):
+        """`strength_alpha`: the 0.1 of :820; the demo's copy of this net takes it as an argument
+        (show_demo/utils_demo.py:30: x_c + strength_alpha * (mapper_all(...) - x_c))."""
         out = []
         loss_delta = 0
         for c in range(len(x)):
@@ -232,14 +234,14 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
             if c < self.mapper_layer:
                 x_text_hidden = getattr(self, f"mapper_text_{c}")(x_text).unsqueeze(1)
                 x_c_hidden = getattr(self, f"mapper_{c}")(x_c)
-                x_c_new = x_c + 0.1 * (getattr(self, f"mapper_all_{c}")(torch.cat([x_c_hidden, x_text_hidden], dim=-1)) - x_c)
+                x_c_new = x_c + strength_alpha * (getattr(self, f"mapper_all_{c}")(torch.cat([x_c_hidden, x_text_hidden], dim=-1)) - x_c)
                 loss_delta = loss_delta + torch.mean(torch.norm(x_c_new - x_c, dim=-1)) / float(self.mapper_layer)
                 out.append(x_c_new.unsqueeze(3).unsqueeze(3))
             else:
                 out.append(x_c.unsqueeze(3).unsqueeze(3))
         return out, loss_delta
 
-    def forward(self, x, feature_map, size, attention_text=None):
+    def forward(self, x, feature_map, size, attention_text=None, strength_alpha=0.1):
         if torch.is_grad_enabled() and not self._mask_params_frozen():
             raise RuntimeError("FullSpaceMapperFEATClusterLinStyle_Net: the mask branch (attention*/initial* parameters) is "
                                "forward-only here -- the reference keeps it frozen for the whole run (run_attention.py:1076-1083); "
@@ -249,7 +251,7 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
             attention_text = x_text
         each, assign = self.attention_map(feature_map, size, attention_text.detach().float(), len(x))
         same, means, counts, thr, final = cluster_pool(each, assign, size, self.clusters)
-        out, loss_delta = self.new_styles(x, x_text)
+        out, loss_delta = self.new_styles(x, x_text, strength_alpha)
         # :851-869: sum over non-empty clusters of relu(mean - 0.7), averaged over the batch; :871 MSE(each, same)
         loss_reg = (torch.relu(means - 0.7) * (counts > 0)).sum().reshape(1) / float(each.shape[0])
         loss_tv = F.mse_loss(each, same)
