@@ -161,7 +161,7 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
     net = FullSpaceMapperFEATClusterLinStyle_Net(18, edim + 512, edim, attention_layer=att, channel_multiplier=2, cluster_layer=att,
                                                  clusters=k, cluster_dim=576)
     msd = MA.net_state_dict(net)
-    msd["initial_bias"] = torch.tensor([0.0])
+    msd["initial_bias"] = torch.tensor([0.9])  # about half of the 20 cluster means pass the 0.8 threshold
     img = seeded.tensor("cfg5.img", (1, 3, 256, 256), 0.5)
     text, att_text = seeded.tensor("cfg5.text", (1, edim), 0.3), seeded.tensor("cfg5.att", (1, edim), 0.3)
     # oracle, stage by stage

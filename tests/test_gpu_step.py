@@ -422,3 +422,54 @@ def test_stylespace_region_attention_step_matches_oracle():
     params = dict(coach.net.mapper.named_parameters())
     assert_grad_close(torch.cat([params[n].grad.reshape(-1).cpu() for n in names]), torch.cat([g.reshape(-1) for g in grads_o]),
                       "S-space mapper gradients through the blend")
+
+
+def test_deterministic_mode_gives_bit_identical_steps():
+    """W2E_DETERMINISTIC / where2edit_amd.set_deterministic: two runs of the same mapper step from the same state give
+    bit-identical losses and mapper gradients (the reference sets cudnn.deterministic, run_attention.py:903-904); the
+    default mode (fp32 atomics in split-K and the gradient reductions) agrees with it to rounding."""
+    import where2edit_amd
+    from where2edit_amd import _lib
+
+    def run():
+        coach, _, _ = _coach(_opts())
+        w = seeded.wplus_latents(2, OG.n_latent(SIZE), salt=21).to(DEV)
+        coach.optimizer.zero_grad()
+        x, x_hat, w_hat = coach.forward_pair(w)
+        loss, _ = coach.calc_loss(w, x, w_hat, x_hat)
+        loss.backward()
+        return loss.detach().clone(), torch.cat([p.grad.reshape(-1) for p in coach.net.mapper.parameters()]).clone(), x_hat.detach().clone()
+
+    base = run()
+    where2edit_amd.set_deterministic(True)
+    try:
+        assert _lib.get_option("deterministic") == 1
+        a, b = run(), run()
+    finally:
+        where2edit_amd.set_deterministic(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]), "loss / image differ between two deterministic runs"
+    assert torch.equal(a[1], b[1]), "mapper gradients differ between two deterministic runs"
+    assert_close(a[2], base[2], 1e-5, "deterministic vs default image")
+    assert_grad_close(a[1], base[1], "deterministic vs default gradients", tol=1e-3)
+
+
+def test_deterministic_mode_at_1024_with_vit_b32():
+    """The same at the measured configuration's shapes (1024^2, batch 2, full ViT-B/32): every split-K / atomic site of
+    the big layers and of the ViT GEMMs is on the path."""
+    import bench
+    import where2edit_amd
+    where2edit_amd.set_deterministic(True)
+    try:
+        outs = []
+        for _ in range(2):
+            coach = bench.build_coach(1024, 2, DEV, False, "hip", 2)
+            w = bench.synthetic_latents(coach.net.decoder, 2, 0)
+            coach.optimizer.zero_grad()
+            x, x_hat, w_hat = coach.forward_pair(w)
+            loss, _ = coach.calc_loss(w, x, w_hat, x_hat)
+            loss.backward()
+            outs.append((loss.detach().clone(), torch.cat([p.grad.reshape(-1) for p in coach.net.mapper.parameters()]).clone()))
+            del coach
+    finally:
+        where2edit_amd.set_deterministic(False)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -5,8 +5,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-coach = bench.build_coach(1024, 4, "cuda:0", False, "hip")
-w = bench.synthetic_latents(coach.net.decoder, 4, 0)
+WL = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+coach = bench.build_coach(1024, B, "cuda:0", False, "hip", WL)
+w = bench.synthetic_latents(coach.net.decoder, B, 0)
+mask = torch.rand(B, 1, 64, 64, device="cuda:0") if WL == 3 else None
+_step = coach.train_step
+coach.train_step = lambda w_: _step(w_, mask)
 for _ in range(3):
     coach.train_step(w)
 torch.cuda.synchronize()

@@ -14,3 +14,14 @@ Layout:
   dist.py                 data-parallel step: shard latents, one RCCL all-reduce of mapper grads
 """
 __version__ = "0.1.0"
+
+
+def set_deterministic(enabled=True):
+    """Bit-reproducible results, the counterpart of the reference's `cudnn.deterministic = True`
+    (attention/run_attention.py:903-904): libw2e.so stops using fp32 atomics (no split-K, fixed-order reductions;
+    w2e_set_option("deterministic")) and PyTorch's own ops are switched to their deterministic algorithms (rocBLAS
+    without atomics).  Costs a few percent of throughput; off by default."""
+    import torch
+    from . import _lib
+    _lib.set_option("deterministic", 1 if enabled else 0)
+    torch.use_deterministic_algorithms(bool(enabled), warn_only=True)

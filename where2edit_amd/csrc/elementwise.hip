@@ -316,9 +316,14 @@ __global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict_
     // so it is cut short and spread over the chip); the slices add their part onto gs atomically.
     __shared__ float coef[DEMOD_OCH];
     const int b = blockIdx.y;
-    const int o_lo = blockIdx.z * DEMOD_OCH;
-    const int o_n = (Cout - o_lo < DEMOD_OCH) ? Cout - o_lo : DEMOD_OCH;
     const float nw = noise_w ? noise_w[0] : 0.f;
+    // deterministic mode launches ONE z-slice that walks every output-channel group in order and adds without atomics
+    const bool serial = gridDim.z == 1 && Cout > DEMOD_OCH;
+    const int i_ser = blockIdx.x * 256 + threadIdx.x;
+    float total = 0.f;
+    for (int o_lo = blockIdx.z * DEMOD_OCH; o_lo < Cout; o_lo += DEMOD_OCH) {
+    const int o_n = (Cout - o_lo < DEMOD_OCH) ? Cout - o_lo : DEMOD_OCH;
+    __syncthreads();
     for (int oo = threadIdx.x; oo < o_n; oo += 256) {
         const int o = o_lo + oo;
         float dz;
@@ -334,12 +339,19 @@ __global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict_
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Cin) return;
     float acc = 0.f;
-    const float* wq = wsq + (int64_t)o_lo * Cin + i;
+    if (i < Cin) {
+        const float* wq = wsq + (int64_t)o_lo * Cin + i;
 #pragma unroll 16
-    for (int oo = 0; oo < o_n; ++oo) acc += coef[oo] * wq[(int64_t)oo * Cin];
-    atomicAdd(&gs[(int64_t)b * Cin + i], -s[(int64_t)b * Cin + i] * acc);
+        for (int oo = 0; oo < o_n; ++oo) acc += coef[oo] * wq[(int64_t)oo * Cin];
+    }
+    if (!serial) {
+        if (i < Cin) atomicAdd(&gs[(int64_t)b * Cin + i], -s[(int64_t)b * Cin + i] * acc);
+        return;
+    }
+    total += acc;
+    }
+    if (i_ser < Cin) gs[(int64_t)b * Cin + i_ser] += -s[(int64_t)b * Cin + i_ser] * total;
 }
 
 
@@ -374,7 +386,12 @@ __global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __re
                                                                const int4* __restrict__ meta, float* __restrict__ glatent,
                                                                int B, int L, int D, int R) {
     __shared__ float g[32];
-    const int r0 = blockIdx.x * 32, b = blockIdx.y;
+    const int b = blockIdx.y;
+    // deterministic mode: ONE block per batch element walks every 32-row group in order (plain read-modify-write by the
+    // owning thread); default: one block per group, joined by atomics
+    const bool serial = gridDim.x == 1 && R > 32;
+    for (int r0 = blockIdx.x * 32; r0 < R; r0 += 32) {
+    __syncthreads();
     if (threadIdx.x < 32) {
         const int r = r0 + threadIdx.x;
         float v = 0.f;
@@ -391,7 +408,10 @@ __global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __re
         float acc = 0.f;
 #pragma unroll 8
         for (int i = 0; i < nr; ++i) acc += g[i] * w[(int64_t)(r0 + i) * D + k];
-        atomicAdd(&glatent[((int64_t)b * L + widx) * D + k], acc);
+        if (serial) glatent[((int64_t)b * L + widx) * D + k] += acc;
+        else atomicAdd(&glatent[((int64_t)b * L + widx) * D + k], acc);
+    }
+    if (!serial) break;
     }
 }
 
@@ -442,7 +462,7 @@ int w2e_bias_act_bwd_reduce(const float* gy, const float* y, const float* noise,
     if (rows == 0 || inner == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     int splits = 1;
-    if (rows < 2048) {
+    if (rows < 2048 && !options().deterministic) {  // deterministic: one block owns a row's sums (no atomics)
         splits = (int)ceil_div(2048, rows);
         const int64_t max_splits = ceil_div(inner, 1024);
         if (splits > max_splits) splits = (int)max_splits;
@@ -481,6 +501,11 @@ int w2e_mask_blend_bwd(const float* gout, const float* a, const float* b, const 
         set_error("mask_blend_bwd: memset failed");
         return 2;
     }
+    // gmask: one atomic per pixel into its mask cell.  With the mask at the layer's resolution (the shipped setting:
+    // attention_layer 13 = 64x64 features, 64x64 mask) every cell receives exactly ONE add: order-free.  Otherwise the
+    // adds of a cell's pixels race; the deterministic mode refuses that geometry instead of giving run-to-run noise.
+    W2E_REQUIRE(!(options().deterministic && gmask && (h != ms || w != ms)),
+                "mask_blend_bwd: deterministic mode needs the mask at the feature resolution (%dx%d vs %d)", h, w, ms);
     const int threads = w >= 256 ? 256 : (w >= 128 ? 128 : 64);
     mask_blend_bwd_kernel<<<batch * h, threads, 0, s>>>(gout, a, b, mask, ga, gb, gmask, channels, h, w, ms);
     W2E_LAUNCH_CHECK("mask_blend_bwd");
@@ -522,7 +547,7 @@ int w2e_demod_bwd(const float* sums, const float* dz, const float* noise_w, cons
     W2E_REQUIRE(d && s && wsq && gs, "demod_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && cin > 0 && cout > 0 && batch < 65536, "demod_bwd: bad dims");
     if (batch == 0) return 0;
-    dim3 grid((unsigned)ceil_div(cin, 256), (unsigned)batch, (unsigned)ceil_div(cout, DEMOD_OCH));
+    dim3 grid((unsigned)ceil_div(cin, 256), (unsigned)batch, options().deterministic ? 1u : (unsigned)ceil_div(cout, DEMOD_OCH));
     demod_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sums, dz, noise_w, bias, d, s, wsq, gs, gd, cin, cout);
     W2E_LAUNCH_CHECK("demod_bwd");
     return 0;
@@ -568,7 +593,7 @@ int w2e_style_affine_bwd(const float* gout, const float* w, const int* meta, flo
         set_error("style_affine_bwd: memset failed");
         return 2;
     }
-    dim3 grid((unsigned)ceil_div(rows, 32), (unsigned)batch);
+    dim3 grid(options().deterministic ? 1u : (unsigned)ceil_div(rows, 32), (unsigned)batch);
     style_affine_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gout, w, reinterpret_cast<const int4*>(meta), glatent, batch,
                                                                  n_latent, dim, rows);
     W2E_LAUNCH_CHECK("style_affine_bwd");

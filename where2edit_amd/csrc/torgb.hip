@@ -209,7 +209,7 @@ extern "C" int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float*
     const int64_t hw = (int64_t)h * w;
     const int64_t waves = (int64_t)batch * cin;
     int splits = 1;
-    if (waves < 8192) {
+    if (waves < 8192 && !options().deterministic) {  // deterministic: one wave owns a (b, channel)'s weight gradient
         splits = (int)ceil_div(8192, waves);
         const int64_t max_splits = ceil_div(hw, 4096);
         if (splits > max_splits) splits = (int)max_splits;

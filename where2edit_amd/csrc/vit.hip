@@ -481,6 +481,7 @@ extern "C" int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int 
             if (sp == 1 || cost < best * 0.97) best = cost, splits = sp;
         }
         if (tune_s > 0) splits = tune_s;
+        if (options().deterministic) splits = 1;  // no fp32 atomics onto C
     }
     const int k_per = (int)(ceil_div(ceil_div(k, splits), 2 * GBK) * 2 * GBK);  // an even number of 64-deep steps
     splits = (int)ceil_div(k, k_per);

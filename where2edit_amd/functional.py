@@ -151,6 +151,23 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     return y, dot
 
 
+def _channel_dot(a, b):
+    """[B,C] = sum_p a*b per plane (w2e_channel_sums: one wave per plane, fixed reduction order)."""
+    n, c = a.shape[0], a.shape[1]
+    out = torch.empty((n, c), device=a.device, dtype=torch.float32)
+    call("w2e_channel_sums", ptr(a), ptr(b), ptr(out), n, c, a.shape[2] * a.shape[3], stream_ptr())
+    return out
+
+
+def _scale_planes(a, s):
+    """a[b,c,:,:] * s[b,c]  (w2e_se_apply_bwd with a zero offset)."""
+    n, c = a.shape[0], a.shape[1]
+    out = torch.empty_like(a)
+    zero = torch.zeros((n, c), device=a.device, dtype=torch.float32)
+    call("w2e_se_apply_bwd", ptr(a), ptr(_c(s)), ptr(zero), ptr(out), n, c, a.shape[2] * a.shape[3], stream_ptr())
+    return out
+
+
 def demod_coefficients(s, wsq, eps=1e-8):
     """d[b,o] = rsqrt(sum_i s[b,i]^2 wsq[o,i] + eps) (w2e_demod_fwd)."""
     b, cin = s.shape
@@ -221,10 +238,16 @@ class _StyledConv(torch.autograd.Function):
         if upsample:
             # adjoint of Blur(pad=(1,1)) back onto the (2h+1)x(2w+1) transposed-conv grid, then the
             # stride-2 conv that is the adjoint of conv_transpose2d
-            gt = _upfirdn2d_raw(gpre, blur_kernel, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
-            gx, gs = _modconv_raw(MODE_DOWN, gt, wp_b, d, s, h, w, dot_with=x)
+            gpre = _upfirdn2d_raw(gpre, blur_kernel, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
+        mode = MODE_DOWN if upsample else MODE_SAME
+        if _lib.get_option("deterministic"):
+            # the fused dot epilogue joins the workgroups of a (b, channel) with fp32 atomics; here instead: the unscaled
+            # input gradient, its per-channel dot with x by a fixed-order wave reduction, then the out_scale
+            raw, _ = _modconv_raw(mode, gpre, wp_b, d, None, h, w)
+            gs = _channel_dot(raw, x)
+            gx = _scale_planes(raw, s)
         else:
-            gx, gs = _modconv_raw(MODE_SAME, gpre, wp_b, d, s, h, w, dot_with=x)
+            gx, gs = _modconv_raw(mode, gpre, wp_b, d, s, h, w, dot_with=x)
         if d is not None:  # + the demodulation path: gs -= s * (dz*d^2) @ wsq, with dz = sum_p gpre*(pre - nw*noise - bias)
             call("w2e_demod_bwd", ptr(sums), ptr(dz), ptr(noise_w) if (fuse_act and noise is not None) else None,
                  ptr(bias) if fuse_act else None, ptr(d), ptr(s), ptr(wsq), ptr(gs), None, b, cin, cout, stream_ptr())
