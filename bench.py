@@ -216,6 +216,9 @@ def main():
                     help="the roofline's HIP events are recorded on every N-th timed step (166 timed event records per step "
                          "cost the step 5 %%: 159 images/s without them, 150 with them on every step)")
     ap.add_argument("--no-preview", action="store_true", help="skip the extra K steps in the opt-in bf16x3 conv precision (N=1 only)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph (Coach.capture_step) instead of ~330 eager launches; the "
+                         "per-kernel HIP-event roofline is then taken from eager steps run beside the timed region")
     ap.add_argument("--synthetic-mask", action="store_true", help="workload 3: a seeded U(0,1) mask instead of the region-attention net's")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank; default) or gloo (self-test: the ranks may share a GPU)")
@@ -284,24 +287,44 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    stab_steps, stab_ok = (0, False) if args.no_stabilise else stabilise(lambda: coach.train_step(w, mask))
+    step_fn = lambda: coach.train_step(w, mask)  # noqa: E731
+    if args.graph:
+        if callable(mask):
+            raise SystemExit("--graph needs a tensor mask (--synthetic-mask with --workload 3)")
+        graphed = coach.capture_step(w, mask)
+        step_fn = lambda: graphed(w, mask)  # noqa: E731
+    stab_steps, stab_ok = (0, False) if args.no_stabilise else stabilise(step_fn)
     for _ in range(args.warmup):
-        coach.train_step(w, mask)
+        step_fn()
     barrier()
     timer = None if args.no_kernel_timing else profiling.KernelTimer()
-    if timer is not None:
-        timer.__enter__()
-    t0 = time.perf_counter()
     sampled = 0
-    for i in range(args.steps):
-        if timer is not None:  # HIP events around the conv / blur launches on every `--timing-stride`-th timed step
-            timer.enabled = i % args.timing_stride == 0
-            sampled += int(timer.enabled)
-        last = coach.train_step(w, mask)
-    barrier()
-    dt = time.perf_counter() - t0
-    if timer is not None:
-        timer.__exit__(None, None, None)
+    if args.graph:  # the timed region is graph replays only; the per-kernel roofline comes from eager steps after it
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if timer is not None:
+            timer.__enter__()
+            for i in range(max(1, args.steps // args.timing_stride)):
+                coach.train_step(w, mask)
+                sampled += 1
+            barrier()
+            timer.__exit__(None, None, None)
+    else:
+        if timer is not None:
+            timer.__enter__()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if timer is not None:  # HIP events around the conv / blur launches on every `--timing-stride`-th timed step
+                timer.enabled = i % args.timing_stride == 0
+                sampled += int(timer.enabled)
+            last = step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if timer is not None:
+            timer.__exit__(None, None, None)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -327,7 +350,7 @@ def main():
                                 f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
                    "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
-                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "dist_backend": args.dist_backend if world > 1 else None},
+                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "dist_backend": args.dist_backend if world > 1 else None},
     }
     if timer is not None:
         s = timer.summary()

@@ -473,3 +473,25 @@ def test_deterministic_mode_at_1024_with_vit_b32():
     finally:
         where2edit_amd.set_deterministic(False)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_graphed_step_equals_eager_step():
+    """Coach.capture_step: the step replayed as one hipGraph gives the same losses, gradients and post-Ranger parameters as
+    the eager step -- bit for bit in deterministic mode -- over several steps with changing latents (the static input
+    buffer is refilled before every replay), including the look-ahead step of Ranger (k = 6) that runs outside the graph."""
+    import where2edit_amd
+    where2edit_amd.set_deterministic(True)
+    try:
+        eager, _, _ = _coach(_opts())
+        graphed, _, _ = _coach(_opts())
+        ws = [seeded.wplus_latents(2, OG.n_latent(SIZE), salt=60 + i).to(DEV) for i in range(7)]
+        step = graphed.capture_step(ws[0])
+        for i, w in enumerate(ws):
+            de = eager.train_step(w)
+            dg = step(w)
+            assert torch.equal(de["loss"], dg["loss"]), f"loss at step {i}"
+            for (n, pe), (_, pg) in zip(eager.net.mapper.named_parameters(), graphed.net.mapper.named_parameters()):
+                assert torch.equal(pe, pg), f"{n} after step {i}"
+        assert graphed.global_step == 7
+    finally:
+        where2edit_amd.set_deterministic(False)

@@ -156,6 +156,67 @@ class Coach:
         self.global_step += 1
         return loss_dict
 
+    # ---- the fixed-shape step as ONE hipGraph launch -------------------------------------------------------------
+    def capture_step(self, w, mask=None, warmup=3):
+        """Capture zero-grad + forward_pair + calc_loss + backward for inputs of w's shape into a hipGraph (about 330
+        kernel / memset nodes at 1024^2) and return `step(w[, mask]) -> loss_dict`, which copies the inputs into the
+        graph's static buffers, replays it, then runs the gradient all-reduce and the optimizer eagerly (Ranger's
+        rectification and look-ahead are host-side control flow, ranger.py:124-161).  The libw2e.so entry points are
+        capture-safe (stream-ordered, no allocation, no synchronisation; include/w2e.h); `warmup` eager iterations on the
+        capture stream first build every lazily cached pack and opt the large-LDS kernels in on this device."""
+        from . import profiling
+        if profiling._active is not None:
+            raise RuntimeError("capture_step: per-kernel HIP-event timing cannot be recorded inside a graph")
+        if callable(mask):
+            raise RuntimeError("capture_step: pass the mask tensor (a callable mask is evaluated eagerly)")
+        s_space = getattr(self.opts, "work_in_stylespace", False)
+        static_w = [c.clone() for c in w] if s_space else w.clone()
+        static_mask = mask.clone() if mask is not None else None
+        params = list(self.net.mapper.parameters())
+
+        def body():
+            if self.bucket is not None:
+                self.bucket.zero()
+            else:
+                for p in params:  # static .grad tensors, zeroed in place: the graph's nodes keep pointing at them
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    else:
+                        p.grad.zero_()
+            x, x_hat, w_hat = self.forward_pair(static_w, static_mask)
+            loss, loss_dict = self.calc_loss(static_w, x, w_hat, x_hat)
+            loss.backward()
+            return loss_dict
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = body()
+
+        def step(w_new, mask_new=None):
+            if s_space:
+                for dst, src in zip(static_w, w_new):
+                    dst.copy_(src)
+            else:
+                static_w.copy_(w_new)
+            if static_mask is not None and mask_new is not None:
+                static_mask.copy_(mask_new)
+            graph.replay()
+            if self.bucket is not None:
+                self.bucket.all_reduce_mean()
+            self.optimizer.step()
+            self.global_step += 1
+            return static_out
+
+        step.graph = graph
+        return step
+
     def train(self, latents, max_steps=None, generator=None):
         """Epochs over a [N,18,512] latent tensor: shuffle, batch_size, drop_last (coach.py:44-48,70-79)."""
         self.net.train()

@@ -1033,6 +1033,9 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int wp2 = next_pow2(w);
     int best = -1, best_splits = 1;
     double best_cost = 0.0;
+    // no split-K with the bias/PReLU epilogue (it needs the complete sum) nor in deterministic mode (no fp32 atomics): the
+    // tile is then chosen among the unsplit candidates, not chosen for a split and stripped of it afterwards
+    const int sp_max = (prelu || opt.deterministic) ? 1 : 32;
     for (int c = 0; c < ncfg; ++c) {
         const int tn = 32 * cfgs[c].nob * cfgs[c].wo, tm = 32 * cfgs[c].npb * cfgs[c].wp;
         const int tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
@@ -1054,7 +1057,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
         const double t_stage0 = (double)ceil_div(k_ch, kc) * 1200.0;
         // split-K (low resolutions: a handful of tiles, each a K*9/2-long dependent MFMA chain): S slices of the
         // channel range per tile, summed with fp32 atomics onto a zeroed output
-        for (int sp = 1; sp <= 32; sp *= 2) {
+        for (int sp = 1; sp <= sp_max; sp *= 2) {
             if (sp > 1 && (k_ch / sp < 2 * kc_max || (up ? 4.0 : 1.0) * tiles * (sp / 2) >= 256.0)) break;
             double cost;
             // a lone 256-thread workgroup on a CU has nobody to hide its staging behind (1 wave per SIMD)
@@ -1097,7 +1100,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
             const double tiles = (double)batch * ceil_div(n_ch, tn) * ceil_div(h, th) * ceil_div(w, tw);
             const double unit = (double)cfgs[c].nob * (cfgs[c].npb / 4) * (nt / 256.0) * (k_ch / 2.0) * 64.0;  // one tap
             const double t_stage = (double)ceil_div(k_ch, kc) * 1200.0;
-            for (int sp = 1; sp <= 32; sp *= 2) {
+            for (int sp = 1; sp <= sp_max; sp *= 2) {
                 if (sp > 1 && (k_ch / sp < 2 * kc || tiles * (sp / 2) >= 256.0)) break;
                 // a split adds the memset and the fp32 atomics: ~120 cycles per 256-B wave-instruction per CU
                 const double atomics = sp > 1 ? (double)tn * tm * 4.0 / 64.0 * 120.0 : 0.0;

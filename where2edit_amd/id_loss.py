@@ -145,7 +145,8 @@ class IDLoss(nn.Module):
             # takes part in the backward (y's features are detached in the reference, id_loss.py:33)
             from . import functional as K
             n = y_hat.shape[0]
-            feats = self.facenet(K.id_preprocess(torch.cat([y_hat, y.detach()])), n_grad=n)
+            faces = torch.cat([K.id_preprocess(y_hat), K.id_preprocess(y.detach())])  # (cat the 112^2 crops, not the images)
+            feats = self.facenet(faces, n_grad=n)
             y_hat_feats, y_feats = feats[:n], feats[n:].detach()
         else:
             y_feats = self.extract_feats(y).detach()
