@@ -54,6 +54,12 @@ static inline bool big_lds_once(const void* fn, unsigned* done_mask) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zero `bytes` (a multiple of 4) at a 4-byte aligned device address with a KERNEL on stream s.  Used instead of
+// hipMemsetAsync everywhere in the library: under stream capture (Coach.capture_step) a memset issued from here was not
+// replayed with the graph on this ROCm (split-K outputs then accumulated onto the previous replay's values), while kernel
+// nodes always are.
+hipError_t zero_async(void* p, size_t bytes, hipStream_t s);
+
 // Memory-bound kernels: cap the grid and grid-stride (256 CUs x 8 blocks).
 static inline int stream_grid(int64_t work_items, int block) {
     int64_t g = ceil_div(work_items, block);

@@ -469,7 +469,7 @@ int w2e_bias_act_bwd_reduce(const float* gy, const float* y, const float* noise,
         if (splits < 1) splits = 1;
     }
     W2E_REQUIRE(rows * splits < (int64_t)1 << 31, "bias_act_bwd_reduce: grid too large");
-    if (splits > 1 && hipMemsetAsync(sums, 0, sizeof(float) * 3 * rows, s) != hipSuccess) {
+    if (splits > 1 && zero_async(sums, sizeof(float) * 3 * rows, s) != hipSuccess) {
         set_error("bias_act_bwd_reduce: memset failed");
         return 2;
     }
@@ -497,7 +497,7 @@ int w2e_mask_blend_bwd(const float* gout, const float* a, const float* b, const 
     W2E_REQUIRE(batch >= 0 && channels > 0 && h > 0 && w > 0 && ms > 0, "mask_blend_bwd: bad dims");
     if (batch == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (gmask && hipMemsetAsync(gmask, 0, sizeof(float) * (size_t)batch * ms * ms, s) != hipSuccess) {
+    if (gmask && zero_async(gmask, sizeof(float) * (size_t)batch * ms * ms, s) != hipSuccess) {
         set_error("mask_blend_bwd: memset failed");
         return 2;
     }
@@ -589,7 +589,7 @@ int w2e_style_affine_bwd(const float* gout, const float* w, const int* meta, flo
     W2E_REQUIRE(gout && w && meta && glatent, "style_affine_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && batch < 65536 && n_latent > 0 && dim > 0 && rows > 0, "style_affine_bwd: bad dims");
     if (batch == 0) return 0;
-    if (hipMemsetAsync(glatent, 0, sizeof(float) * (size_t)batch * n_latent * dim, (hipStream_t)stream) != hipSuccess) {
+    if (zero_async(glatent, sizeof(float) * (size_t)batch * n_latent * dim, (hipStream_t)stream) != hipSuccess) {
         set_error("style_affine_bwd: memset failed");
         return 2;
     }

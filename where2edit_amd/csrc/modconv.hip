@@ -1218,11 +1218,11 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
             stamp_cap = grid, stamp_buf = nullptr;
             if (hipMalloc((void**)&stamp_buf, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)stamp_cap) != hipSuccess) stamp_buf = nullptr, stamp_cap = 0;
         }
-        if (stamp_buf && hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid, s) == hipSuccess) p.stamps = stamp_buf, stamped = true;
+        if (stamp_buf && zero_async(stamp_buf, sizeof(unsigned long long) * STAMP_STRIDE * (size_t)grid, s) == hipSuccess) p.stamps = stamp_buf, stamped = true;
     }
 #endif
     if (p.splits > 1 &&
-        hipMemsetAsync(y, 0, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
+        zero_async(y, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
         return 2;
     }

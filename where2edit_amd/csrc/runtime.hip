@@ -64,6 +64,29 @@ static OptionsInit g_opt_init;  // runs when the shared library is loaded
 
 const Options& options() { return g_opt; }
 
+__global__ void zero_kernel(unsigned* __restrict__ p, size_t words) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += step) p[i] = 0u;
+}
+
+__global__ void zero4_kernel(uint4* __restrict__ p, size_t quads) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += step) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) != 0 || ((uintptr_t)p & 3) != 0) return hipErrorInvalidValue;
+    if (((uintptr_t)p & 15) == 0 && (bytes & 15) == 0) {
+        const size_t quads = bytes >> 4;
+        zero4_kernel<<<stream_grid((int64_t)quads, 256), 256, 0, s>>>(reinterpret_cast<uint4*>(p), quads);
+    } else {
+        const size_t words = bytes >> 2;
+        zero_kernel<<<stream_grid((int64_t)words, 256), 256, 0, s>>>(reinterpret_cast<unsigned*>(p), words);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace w2e
 
 extern "C" {

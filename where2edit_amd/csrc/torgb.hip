@@ -217,7 +217,7 @@ extern "C" int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float*
     int64_t per_split = ceil_div(hw, splits);
     per_split = (per_split + 255) & ~int64_t(255);
     splits = (int)ceil_div(hw, per_split);
-    if (splits > 1 && hipMemsetAsync(gwmod, 0, sizeof(float) * 3 * (size_t)batch * cin, s) != hipSuccess) {
+    if (splits > 1 && zero_async(gwmod, sizeof(float) * 3 * (size_t)batch * cin, s) != hipSuccess) {
         set_error("torgb_bwd: memset failed");
         return 2;
     }

@@ -485,7 +485,7 @@ extern "C" int w2e_gemm_ex(const float* a, const float* b, float* c, int m, int 
     }
     const int k_per = (int)(ceil_div(ceil_div(k, splits), 2 * GBK) * 2 * GBK);  // an even number of 64-deep steps
     splits = (int)ceil_div(k, k_per);
-    if (splits > 1 && !c_is_zero && hipMemsetAsync(c, 0, sizeof(float) * (size_t)m * n, s) != hipSuccess) {
+    if (splits > 1 && !c_is_zero && zero_async(c, sizeof(float) * (size_t)m * n, s) != hipSuccess) {
         set_error("gemm: memset failed");
         return 2;
     }
