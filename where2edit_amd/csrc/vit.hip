@@ -237,6 +237,75 @@ __device__ __forceinline__ float wave_sum_ln(float v) {
 
 constexpr int LN_MAX_PER_LANE = 32;  // dim <= 2048
 
+// The ViT widths (dim = 256 * T4: 768 -> T4 = 3): ONE wave per row and per workgroup (rows = 50 * batch workgroups spread
+// over the chip: these kernels are pure latency), the row in registers as T4 float4s per lane, every load of the row issued
+// before the first reduction.
+template <int T4>
+__global__ __launch_bounds__(64) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out, int dim,
+                                                               float eps) {
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * dim);
+    float4 v[T4], g[T4], bt[T4];
+#pragma unroll
+    for (int t = 0; t < T4; ++t) v[t] = xr[lane + 64 * t];
+#pragma unroll
+    for (int t = 0; t < T4; ++t) g[t] = reinterpret_cast<const float4*>(gamma)[lane + 64 * t], bt[t] = reinterpret_cast<const float4*>(beta)[lane + 64 * t];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < T4; ++t) s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    const float mean = wave_sum_ln(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < T4; ++t) {
+        v[t].x -= mean, v[t].y -= mean, v[t].z -= mean, v[t].w -= mean;
+        q += (v[t].x * v[t].x + v[t].y * v[t].y) + (v[t].z * v[t].z + v[t].w * v[t].w);
+    }
+    const float rstd = rsqrtf(wave_sum_ln(q) / dim + eps);
+    float4* yr = reinterpret_cast<float4*>(y + row * dim);
+#pragma unroll
+    for (int t = 0; t < T4; ++t)
+        yr[lane + 64 * t] = make_float4(v[t].x * rstd * g[t].x + bt[t].x, v[t].y * rstd * g[t].y + bt[t].y, v[t].z * rstd * g[t].z + bt[t].z,
+                                        v[t].w * rstd * g[t].w + bt[t].w);
+    if (lane == 0) mean_out[row] = mean, rstd_out[row] = rstd;
+}
+
+template <int T4>
+__global__ __launch_bounds__(64) void layernorm_bwd_vec_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ add,
+                                                               float* __restrict__ gx, int dim) {
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const float4* gr = reinterpret_cast<const float4*>(gy + row * dim);
+    const float4* xr = reinterpret_cast<const float4*>(x + row * dim);
+    const float4* ar = add ? reinterpret_cast<const float4*>(add + row * dim) : nullptr;
+    float4 gg[T4], xh[T4], ad[T4];
+#pragma unroll
+    for (int t = 0; t < T4; ++t) gg[t] = gr[lane + 64 * t], xh[t] = xr[lane + 64 * t];
+#pragma unroll
+    for (int t = 0; t < T4; ++t) ad[t] = ar ? ar[lane + 64 * t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < T4; ++t) {
+        const float4 gm = reinterpret_cast<const float4*>(gamma)[lane + 64 * t];
+        gg[t].x *= gm.x, gg[t].y *= gm.y, gg[t].z *= gm.z, gg[t].w *= gm.w;
+        xh[t].x = (xh[t].x - mu) * rs, xh[t].y = (xh[t].y - mu) * rs, xh[t].z = (xh[t].z - mu) * rs, xh[t].w = (xh[t].w - mu) * rs;
+        s1 += (gg[t].x + gg[t].y) + (gg[t].z + gg[t].w);
+        s2 += (gg[t].x * xh[t].x + gg[t].y * xh[t].y) + (gg[t].z * xh[t].z + gg[t].w * xh[t].w);
+    }
+    s1 = wave_sum_ln(s1) / dim;
+    s2 = wave_sum_ln(s2) / dim;
+    float4* out = reinterpret_cast<float4*>(gx + row * dim);
+#pragma unroll
+    for (int t = 0; t < T4; ++t)
+        out[lane + 64 * t] = make_float4(rs * (gg[t].x - s1 - xh[t].x * s2) + ad[t].x, rs * (gg[t].y - s1 - xh[t].y * s2) + ad[t].y,
+                                         rs * (gg[t].z - s1 - xh[t].z * s2) + ad[t].z, rs * (gg[t].w - s1 - xh[t].w * s2) + ad[t].w);
+}
+
 // One wave per row; the row is held in registers (two-pass mean / variance, like F.layer_norm).
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
@@ -518,7 +587,12 @@ extern "C" int w2e_layernorm_fwd(const float* x, const float* gamma, const float
     W2E_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null tensor");
     W2E_REQUIRE(dim > 0 && dim <= 64 * LN_MAX_PER_LANE, "layernorm_fwd: dim %d unsupported (max %d)", dim, 64 * LN_MAX_PER_LANE);
     if (rows <= 0) return 0;
-    layernorm_fwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, mean, rstd, rows, dim, eps);
+    const bool al = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) && rows < ((int64_t)1 << 31);
+    hipStream_t st = (hipStream_t)stream;
+    if (al && dim == 768) layernorm_fwd_vec_kernel<3><<<(unsigned)rows, 64, 0, st>>>(x, gamma, beta, y, mean, rstd, dim, eps);
+    else if (al && dim == 512) layernorm_fwd_vec_kernel<2><<<(unsigned)rows, 64, 0, st>>>(x, gamma, beta, y, mean, rstd, dim, eps);
+    else if (al && dim == 1024) layernorm_fwd_vec_kernel<4><<<(unsigned)rows, 64, 0, st>>>(x, gamma, beta, y, mean, rstd, dim, eps);
+    else layernorm_fwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, st>>>(x, gamma, beta, y, mean, rstd, rows, dim, eps);
     W2E_LAUNCH_CHECK("layernorm_fwd");
     return 0;
 }
@@ -528,7 +602,13 @@ extern "C" int w2e_layernorm_bwd_add(const float* gy, const float* x, const floa
     W2E_REQUIRE(gy && x && gamma && mean && rstd && gx, "layernorm_bwd: null tensor");
     W2E_REQUIRE(dim > 0 && dim <= 64 * LN_MAX_PER_LANE, "layernorm_bwd: dim %d unsupported", dim);
     if (rows <= 0) return 0;
-    layernorm_bwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, (hipStream_t)stream>>>(gy, x, gamma, mean, rstd, add, gx, rows, dim);
+    const bool al = ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)gx | (uintptr_t)(add ? add : x)) & 15) == 0) &&
+                    rows < ((int64_t)1 << 31);
+    hipStream_t st = (hipStream_t)stream;
+    if (al && dim == 768) layernorm_bwd_vec_kernel<3><<<(unsigned)rows, 64, 0, st>>>(gy, x, gamma, mean, rstd, add, gx, dim);
+    else if (al && dim == 512) layernorm_bwd_vec_kernel<2><<<(unsigned)rows, 64, 0, st>>>(gy, x, gamma, mean, rstd, add, gx, dim);
+    else if (al && dim == 1024) layernorm_bwd_vec_kernel<4><<<(unsigned)rows, 64, 0, st>>>(gy, x, gamma, mean, rstd, add, gx, dim);
+    else layernorm_bwd_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, st>>>(gy, x, gamma, mean, rstd, add, gx, rows, dim);
     W2E_LAUNCH_CHECK("layernorm_bwd");
     return 0;
 }
