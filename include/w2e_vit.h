@@ -47,6 +47,34 @@ int w2e_attn_fwd(const float* qkv, float* out, int batch, int seq, int heads, vo
 /* gqkv [B,L,3,heads,64] from gout [B,L,heads*64]; probabilities are recomputed from qkv. */
 int w2e_attn_bwd(const float* qkv, const float* gout, float* gqkv, int batch, int seq, int heads, void* stream);
 
+/* ---- second generation, shaped for M = 50*batch rows (csrc/vit2.hip) ----------------------------------------------------
+ * w2e_gemm_fm:  C[M,N] = A[M,K] x B[N,K]^T  (both operands row-major with K contiguous: nn.Linear's weight for the forward,
+ * its cached transpose for the input gradient).  One workgroup holds ALL rows of a 224-row M tile (7 waves x 32 rows) and 32
+ * columns; K is split over `splits` slices.  epi:
+ *   0 PLAIN      c = acc + bias                                   (splits = 1)
+ *   1 PARTIAL    c[z] = acc of K-slice z, one [M, ldc] slab per slice (slab stride M*ldc), no bias: the CONSUMER sums the
+ *                slabs (w2e_reduce_ln_fwd, w2e_layernorm_bwd_part, w2e_attn2_*) -- no atomics, no memset, deterministic
+ *   2 GELU_DUAL  c = acc + bias, c2 = QuickGELU(c)                (c_fc: the pre-activation is kept for the backward)
+ *   3 GELU_GRAD  c = acc * QuickGELU'(aux)                        (input gradient through c_proj and the activation)
+ * K % 32 == 0, lda/ldb % 4 == 0, 16-byte aligned operands.  w2e_gemm_fm_splits suggests `splits` for a shape. */
+int w2e_gemm_fm_splits(int m, int n, int k, int allow_split);
+int w2e_gemm_fm(const float* a, const float* b, float* c, float* c2, int m, int n, int k, int lda, int ldb, int ldc, int splits,
+                int epi, const float* bias, const float* aux, void* stream);
+/* x = sum_{s<nsplit} part[s] (+ bias[dim]) (+ residual) -> x_out (may be NULL);  y = LayerNorm(x)*gamma + beta with mean / rstd
+ * saved (y may be NULL: reduction only).  part: nsplit slabs of [rows, dim], `slab` elements apart.  dim in {512, 768, 1024}. */
+int w2e_reduce_ln_fwd(const float* part, int nsplit, int64_t slab, const float* bias, const float* residual, float* x_out,
+                      const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int dim, float eps,
+                      void* stream);
+/* gx = LN'(sum_s gpart[s]) + add   (add may be NULL). */
+int w2e_layernorm_bwd_part(const float* gpart, int nsplit, int64_t slab, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, const float* add, float* gx, int64_t rows, int dim, void* stream);
+/* The attention core on MFMA.  qkv = sum of nsplit slabs [B*L, 3*heads*64] (+ bias[3*heads*64]); out [B*L, heads*64].
+ * Backward: gout = sum of gsplit slabs [B*L, heads*64]; gqkv [B*L, 3*heads*64] (probabilities recomputed). */
+int w2e_attn2_fwd(const float* qkv, int nsplit, int64_t slab, const float* bias, float* out, int batch, int seq, int heads,
+                  void* stream);
+int w2e_attn2_bwd(const float* qkv, int nsplit, int64_t slab, const float* bias, const float* gout, int gsplit, int64_t gslab,
+                  float* gqkv, int batch, int seq, int heads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

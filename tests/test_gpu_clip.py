@@ -122,3 +122,93 @@ def test_clip_loss_1024_vs_oracle():
     (go,) = torch.autograd.grad(ref.sum(), io)
     assert_close(gi, go, 2e-3, "d loss / d image")
     assert loss(ig, tokens.to(DEV)) is not None and m._text_cache is not None
+
+
+# ---------------------------------------------------------------------------------------------- second-generation kernels
+@pytest.mark.parametrize("m,n,k", [(200, 2304, 768), (200, 768, 3072), (400, 3072, 768), (200, 768, 768), (37, 40, 64), (230, 96, 160), (4, 512, 768)])
+def test_gemm_fm_vs_torch(m, n, k):
+    """w2e_gemm_fm (whole-M workgroups, LDS-DMA ring, split-K slabs) in every epilogue, incl. two M tiles (m > 224),
+    ragged N and M, and every split count that divides K into 32-deep steps."""
+    from where2edit_amd import vit_hip as V
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    w = torch.randn(n, k, generator=g).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    ref = a.double() @ w.double().t()
+    tol = 2e-6 * (k ** 0.5)
+    assert_close(V._gemm_fm(a, w, V.EPI_PLAIN, bias=bias), ref + bias.double(), tol, "plain")
+    steps = k // 32
+    for sp in (1, 2, 3, 6, V._fm_splits(m, n, k)):
+        if sp > steps or -(-steps // (-(-steps // sp))) != sp:
+            continue
+        slabs = V._gemm_fm(a, w, V.EPI_PARTIAL, splits=sp)
+        assert slabs.shape == (sp, m, n)
+        assert_close(slabs.double().sum(0), ref, tol, f"partial x{sp}")
+    c, c2 = V._gemm_fm(a, w, V.EPI_GELU_DUAL, bias=bias)
+    h = ref + bias.double()
+    assert_close(c, h, tol, "gelu-dual c"), assert_close(c2, h * torch.sigmoid(1.702 * h), tol, "gelu-dual gelu(c)")
+    aux = torch.randn(m, n, generator=g).to(DEV)
+    s = torch.sigmoid(1.702 * aux.double())
+    assert_close(V._gemm_fm(a, w, V.EPI_GELU_GRAD, aux=aux), ref * (s * (1 + 1.702 * aux.double() * (1 - s))), 1e-5, "gelu-grad")
+
+
+def test_reduce_ln_and_attention_v2_vs_torch():
+    from where2edit_amd import vit_hip as V
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    for dim in (768, 512, 1024):
+        m = 150
+        part = torch.randn(3, m, dim, generator=g).to(DEV)
+        bias, res = torch.randn(dim, generator=g).to(DEV), torch.randn(m, dim, generator=g).to(DEV)
+        gamma, beta = (torch.randn(dim, generator=g) * 0.2 + 1).to(DEV), (torch.randn(dim, generator=g) * 0.2).to(DEV)
+        x, y, mean, rstd = V._reduce_ln(part, bias, res, gamma, beta, 1e-5)
+        xr = (part.double().sum(0) + bias.double() + res.double()).requires_grad_(True)
+        yr = torch.nn.functional.layer_norm(xr, (dim,), gamma.double(), beta.double(), 1e-5)
+        assert_close(x, xr, 1e-6, "reduced x"), assert_close(y, yr, 1e-5, "LayerNorm of the reduced x")
+        gp = torch.randn(2, m, dim, generator=g).to(DEV)
+        add = torch.randn(m, dim, generator=g).to(DEV)
+        (gref,) = torch.autograd.grad(yr, xr, gp.double().sum(0))
+        assert_close(V._ln_bwd_part(gp, x, gamma, mean, rstd, add), gref + add.double(), 1e-5, "LN backward of summed slabs + add")
+        x2, y2, _, _ = V._reduce_ln(part, None, None, None, None, 0.0, want_y=False)
+        assert y2 is None and torch.allclose(x2.double(), part.double().sum(0), atol=1e-5)
+    for L, H, B, S in ((50, 12, 4, 3), (7, 2, 2, 1), (64, 1, 1, 2), (33, 3, 2, 1)):
+        d3 = 3 * H * 64
+        slabs = torch.randn(S, B * L, d3, generator=g).to(DEV)
+        bias = torch.randn(d3, generator=g).to(DEV)
+        qkv = (slabs.double().sum(0) + bias.double()).view(B, L, d3).requires_grad_(True)
+        q, k, v = qkv.view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref = ((q @ k.transpose(-1, -2) / 8).softmax(-1) @ v).transpose(1, 2).reshape(B * L, H * 64)
+        out = torch.empty(B * L, H * 64, device=DEV)
+        call("w2e_attn2_fwd", ptr(slabs), S, B * L * d3, ptr(bias), ptr(out), B, L, H, stream_ptr())
+        assert_close(out, ref, 1e-5, f"attn2 L={L}")
+        gs = torch.randn(2, B * L, H * 64, generator=g).to(DEV)
+        (gref,) = torch.autograd.grad(ref, qkv, gs.double().sum(0))
+        gq = torch.empty(B * L, d3, device=DEV)
+        call("w2e_attn2_bwd", ptr(slabs), S, B * L * d3, ptr(bias), ptr(gs), 2, B * L * H * 64, ptr(gq), B, L, H, stream_ptr())
+        assert_close(gq, gref.reshape(B * L, d3), 2e-5, f"attn2 grad L={L}")
+
+
+def test_vit_b32_tower_v2_matches_first_generation_and_oracle_gradient(monkeypatch):
+    """The full ViT-B/32 visual tower on the M = 50*batch kernels: features and image gradient against the first-generation
+    kernels (W2E_VIT_V1) and against the CPU oracle, batch 4 (M = 200) and batch 5 (two M tiles)."""
+    cfg = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch=32, context_length=8,
+               vocab_size=64, text_width=64, text_layers=1)
+    m, sd = _model(cfg, "hip")
+    for b in (4, 5):
+        img = seeded.tensor(f"clip.v2.img{b}", (b, 3, 224, 224), 0.5)
+        r = seeded.tensor(f"clip.v2.r{b}", (b, 512))
+        ig = img.to(DEV).requires_grad_(True)
+        f2 = m.encode_image(ig)
+        (g2,) = torch.autograd.grad((f2 * r.to(DEV)).sum(), ig)
+        monkeypatch.setenv("W2E_VIT_V1", "1")
+        i1 = img.to(DEV).requires_grad_(True)
+        f1 = m.encode_image(i1)
+        (g1,) = torch.autograd.grad((f1 * r.to(DEV)).sum(), i1)
+        monkeypatch.delenv("W2E_VIT_V1")
+        assert not torch.equal(f1, f2), "both runs took the same kernels"
+        assert_close(f2, f1, 1e-4, "features v2 vs v1"), assert_close(g2, g1, 1e-3, "image gradient v2 vs v1")
+        if b == 4:
+            io = img.clone().requires_grad_(True)
+            fo = OC.encode_image(sd, io)
+            (go,) = torch.autograd.grad((fo * r).sum(), io)
+            assert_close(f2, fo, 1e-3, "features vs oracle"), assert_close(g2, go, 2e-3, "image gradient vs oracle")

@@ -239,6 +239,139 @@ def resblock_forward(blk, x, heads, arena=None):
                            arena)
 
 
+# ---------------------------------------------------------------------------------------------- second generation
+EPI_PLAIN, EPI_PARTIAL, EPI_GELU_DUAL, EPI_GELU_GRAD = 0, 1, 2, 3
+
+
+_SPLITS = {}
+
+
+def _fm_splits(m, n, k):
+    """K-splits for a gemm_fm shape (w2e_gemm_fm_splits: enough workgroups to fill the chip); 1 in deterministic mode is NOT
+    needed -- the slabs are summed in a fixed order by their consumer."""
+    key = (m, n, k)
+    if key not in _SPLITS:
+        from . import _lib
+        _SPLITS[key] = _lib.load().w2e_gemm_fm_splits(m, n, k, 1)
+    return _SPLITS[key]
+
+
+def _gemm_fm(a, w, epi=EPI_PLAIN, bias=None, aux=None, splits=1):
+    """C = A[M,K] x W[N,K]^T through w2e_gemm_fm.  PARTIAL: returns [splits, M, N] slabs; GELU_DUAL: (c, gelu(c))."""
+    m, k = a.shape
+    n = w.shape[0]
+    dev = a.device
+    c = torch.empty((splits, m, n) if epi == EPI_PARTIAL else (m, n), device=dev, dtype=torch.float32)
+    c2 = torch.empty((m, n), device=dev, dtype=torch.float32) if epi == EPI_GELU_DUAL else None
+    sp = profiling.span("vit_gemm", 2.0 * m * n * k)
+    call("w2e_gemm_fm", ptr(a), ptr(w), ptr(c), ptr(c2), m, n, k, a.stride(0), w.stride(0), n, splits, epi, ptr(bias), ptr(aux),
+         stream_ptr())
+    if sp is not None:
+        sp.end()
+    return (c, c2) if epi == EPI_GELU_DUAL else c
+
+
+def _reduce_ln(part, bias, residual, gamma, beta, eps, want_x=True, want_y=True):
+    """x = sum of the slabs (+ bias + residual); y = LayerNorm(x).  part: [S, M, D]."""
+    s, m, d = part.shape
+    dev = part.device
+    x = torch.empty((m, d), device=dev, dtype=torch.float32) if want_x else None
+    y = mean = rstd = None
+    if want_y:
+        y = torch.empty((m, d), device=dev, dtype=torch.float32)
+        mean = torch.empty(m, device=dev, dtype=torch.float32)
+        rstd = torch.empty(m, device=dev, dtype=torch.float32)
+    call("w2e_reduce_ln_fwd", ptr(part), s, m * d, ptr(bias), ptr(residual), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
+         ptr(rstd), m, d, float(eps), stream_ptr())
+    return x, y, mean, rstd
+
+
+def _ln_bwd_part(gpart, x, gamma, mean, rstd, add):
+    s, m, d = gpart.shape
+    gx = torch.empty((m, d), device=gpart.device, dtype=torch.float32)
+    call("w2e_layernorm_bwd_part", ptr(gpart), s, m * d, ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add), ptr(gx), m, d,
+         stream_ptr())
+    return gx
+
+
+class _WeightsT:
+    """Transposed copies of the frozen Linear weights for the input-gradient GEMMs (gx = gy W = gy (W^T)^T: gemm_fm wants
+    both operands with K contiguous).  +340 MB for ViT-B/32; rebuilt when a weight's version changes."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version)
+        hit = self.cache.get(id(w))
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().t().contiguous())
+            self.cache[id(w)] = hit
+        return hit[1]
+
+
+class _TransformerV2(torch.autograd.Function):
+    """All residual blocks of the visual tower as ONE autograd node on the M = 50*batch kernels (csrc/vit2.hip): per block
+    7 launches forward (reduce+LN, QKV GEMM, attention, out-proj GEMM, reduce+LN, c_fc GEMM with the QuickGELU pair, c_proj
+    GEMM) and 7 backward; split-K slabs are summed by their consumers, never added atomically."""
+
+    @staticmethod
+    def forward(ctx, x, heads, wt, blocks):
+        b, l, dim = x.shape
+        m = b * l
+        x2 = _c(x).reshape(m, dim)
+        saved = []
+        pend, pbias, pres = x2.view(1, m, dim), None, None
+        for blk in blocks:
+            p = _block_params(blk)
+            _frozen(*p)
+            ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b = p
+            xr, y1, mean1, rstd1 = _reduce_ln(pend, pbias, pres, ln1_w, ln1_b, blk.ln_1.eps)
+            qkv = _gemm_fm(y1, in_w, EPI_PARTIAL, splits=_fm_splits(m, 3 * dim, dim))
+            att = torch.empty((m, dim), device=x.device, dtype=torch.float32)
+            call("w2e_attn2_fwd", ptr(qkv), qkv.shape[0], m * 3 * dim, ptr(in_b), ptr(att), b, l, heads, stream_ptr())
+            o = _gemm_fm(att, out_w, EPI_PARTIAL, splits=_fm_splits(m, dim, dim))
+            x_mid, y2, mean2, rstd2 = _reduce_ln(o, out_b, xr, ln2_w, ln2_b, blk.ln_2.eps)
+            h, g = _gemm_fm(y2, fc_w, EPI_GELU_DUAL, bias=fc_b)
+            pend = _gemm_fm(g, proj_w, EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
+            pbias, pres = proj_b, x_mid
+            saved.append((xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h))
+        out, _, _, _ = _reduce_ln(pend, pbias, pres, None, None, 0.0, want_y=False)
+        ctx.saved, ctx.blocks, ctx.wt, ctx.geom = saved, blocks, wt, (b, l, dim, heads)
+        return out.reshape(b, l, dim)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        b, l, dim, heads = ctx.geom
+        m = b * l
+        wt = ctx.wt
+        g = _c(gout).reshape(m, dim)
+        for blk, (xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h) in zip(reversed(ctx.blocks), reversed(ctx.saved)):
+            ln1_w, _, in_w, in_b, out_w, _, ln2_w, _, fc_w, _, proj_w, _ = _block_params(blk)
+            gh = _gemm_fm(g, wt.get(proj_w), EPI_GELU_GRAD, aux=h)                       # through c_proj and QuickGELU'
+            gy2 = _gemm_fm(gh, wt.get(fc_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
+            g_mid = _ln_bwd_part(gy2, x_mid, ln2_w, mean2, rstd2, g)                     # through ln_2, + the residual branch
+            ga = _gemm_fm(g_mid, wt.get(out_w), EPI_PARTIAL, splits=_fm_splits(m, dim, dim))
+            gqkv = torch.empty((m, 3 * dim), device=g.device, dtype=torch.float32)
+            call("w2e_attn2_bwd", ptr(qkv), qkv.shape[0], m * 3 * dim, ptr(in_b), ptr(ga), ga.shape[0], m * dim, ptr(gqkv), b, l, heads,
+                 stream_ptr())
+            gy1 = _gemm_fm(gqkv, wt.get(in_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 3 * dim))
+            g = _ln_bwd_part(gy1, xr, ln1_w, mean1, rstd1, g_mid)                        # through ln_1, + the residual branch
+        ctx.saved = None
+        return g.reshape(b, l, dim), None, None, None
+
+
+def _block_params(blk):
+    return (blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.attn.out_proj.weight,
+            blk.attn.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.mlp.c_proj.weight,
+            blk.mlp.c_proj.bias)
+
+
+def _v2_ok(vit, width):
+    return width in (512, 768, 1024) and width == vit.heads * 64 and not os.environ.get("W2E_VIT_V1")
+
+
 def vision_forward(vit, image):
     """VisionTransformer.forward: patch embed (a GEMM on the re-laid-out image) -> [cls; patches] + pos ->
     ln_pre -> 12 blocks -> ln_post(cls) @ proj."""
@@ -249,8 +382,13 @@ def vision_forward(vit, image):
     b = x.shape[0]
     x = torch.cat([vit.class_embedding.view(1, 1, width).expand(b, 1, width), x], dim=1) + vit.positional_embedding
     x = layer_norm(x, vit.ln_pre)
-    arena = None if os.environ.get("W2E_TUNE_NO_ARENA") else _ZeroArena(len(vit.transformer.resblocks), x.device)
-    for blk in vit.transformer.resblocks:
-        x = resblock_forward(blk, x, vit.heads, arena)
+    if _v2_ok(vit, width):
+        if not hasattr(vit, "_wt"):
+            vit._wt = _WeightsT()
+        x = _TransformerV2.apply(x, vit.heads, vit._wt, list(vit.transformer.resblocks))
+    else:  # widths the M = 50*batch kernels are not instantiated for (the tests' tiny tower): first-generation kernels
+        arena = None if os.environ.get("W2E_TUNE_NO_ARENA") else _ZeroArena(len(vit.transformer.resblocks), x.device)
+        for blk in vit.transformer.resblocks:
+            x = resblock_forward(blk, x, vit.heads, arena)
     x = layer_norm(x[:, 0, :], vit.ln_post)
     return linear(x, vit.proj.t())  # [B,768] x [768,512]
