@@ -60,6 +60,11 @@ int w2e_attn_bwd(const float* qkv, const float* gout, float* gqkv, int batch, in
 int w2e_gemm_fm_splits(int m, int n, int k, int allow_split);
 int w2e_gemm_fm(const float* a, const float* b, float* c, float* c2, int m, int n, int k, int lda, int ldb, int ldc, int splits,
                 int epi, const float* bias, const float* aux, void* stream);
+/* Sum of split-K slabs [rows, n] fused with the QuickGELU pair of the MLP:
+ *   mode 0:  h = sum + bias[n],  g = QuickGELU(h)      (after c_fc)
+ *   mode 1:  h = sum * QuickGELU'(aux)                 (input gradient through the activation; g unused) */
+int w2e_reduce_gelu(const float* part, int nsplit, int64_t slab, const float* bias, const float* aux, float* h, float* g,
+                    int64_t rows, int n, int mode, void* stream);
 /* x = sum_{s<nsplit} part[s] (+ bias[dim]) (+ residual) -> x_out (may be NULL);  y = LayerNorm(x)*gamma + beta with mean / rstd
  * saved (y may be NULL: reduction only).  part: nsplit slabs of [rows, dim], `slab` elements apart.  dim in {512, 768, 1024}. */
 int w2e_reduce_ln_fwd(const float* part, int nsplit, int64_t slab, const float* bias, const float* residual, float* x_out,

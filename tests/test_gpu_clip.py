@@ -212,3 +212,18 @@ def test_vit_b32_tower_v2_matches_first_generation_and_oracle_gradient(monkeypat
             fo = OC.encode_image(sd, io)
             (go,) = torch.autograd.grad((fo * r).sum(), io)
             assert_close(f2, fo, 1e-3, "features vs oracle"), assert_close(g2, go, 2e-3, "image gradient vs oracle")
+
+
+def test_mlp_up_split_paths_vs_torch():
+    """c_fc and its input gradient in the split-K + w2e_reduce_gelu form (what M = 200 takes at N = 3072) and unsplit."""
+    from where2edit_amd import vit_hip as V
+    g = torch.Generator().manual_seed(9)
+    for m in (200, 8):
+        y, w, b = torch.randn(m, 768, generator=g).to(DEV), torch.randn(3072, 768, generator=g).to(DEV) * 0.05, torch.randn(3072, generator=g).to(DEV)
+        h, act = V._mlp_up(y, w, b)
+        href = y.double() @ w.double().t() + b.double()
+        assert_close(h, href, 1e-5, "h"), assert_close(act, href * torch.sigmoid(1.702 * href), 1e-5, "QuickGELU(h)")
+        gy = torch.randn(m, 768, generator=g).to(DEV)
+        wt = torch.randn(3072, 768, generator=g).to(DEV) * 0.05
+        s = torch.sigmoid(1.702 * href)
+        assert_close(V._mlp_up_grad(gy, wt, h), (gy.double() @ wt.double().t()) * (s * (1 + 1.702 * href * (1 - s))), 1e-5, "gelu-grad")

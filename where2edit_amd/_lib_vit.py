@@ -13,6 +13,7 @@ PROTOS = {
     "w2e_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "w2e_gemm_fm_splits": (_I, [_I, _I, _I, _I]),
     "w2e_gemm_fm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "w2e_reduce_gelu": (_I, [_P, _I, _L, _P, _P, _P, _P, _L, _I, _I, _P]),
     "w2e_reduce_ln_fwd": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "w2e_layernorm_bwd_part": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "w2e_attn2_fwd": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P]),

@@ -60,39 +60,53 @@ __global__ __launch_bounds__(64 * FM_WAVES) void gemm_fm_kernel(const GemmFmPara
 
     // ---- DMA roles.  Slot s (0..31) = rows 8s..8s+7 of the stage image (rows 0..223 = A, 224..255 = B), lane l = (row l/8,
     // destination quad l%8) fetching SOURCE quad (l%8)^(l/8).  Rows past M / N fall past the descriptor and land as zeros.
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), (short)0,
-                                                                        (int)((unsigned)p.m * (unsigned)p.lda * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), (short)0,
-                                                                        (int)((unsigned)p.n * (unsigned)p.ldb * 4u), 0x00020000);
     const int lrow = lane >> 3, squad = (lane & 7) ^ lrow;
+    static_assert(FM_WAVES - 1 + FM_WAVES * (FM_SLOTS - 2) < 28 && FM_WAVES * (FM_SLOTS - 1) >= 28, "slot roles");
     unsigned voff[FM_SLOTS];
-    bool is_b[FM_SLOTS];
     unsigned ldst[FM_SLOTS];
 #pragma unroll
     for (int i = 0; i < FM_SLOTS; ++i) {
         const int s = wave + FM_WAVES * i;
         if (s < 28) {
             voff[i] = (unsigned)((m0 + 8 * s + lrow) * p.lda) * 4u + (unsigned)squad * 16u;
-            is_b[i] = false;
         } else if (s < 32) {
             voff[i] = (unsigned)((n0 + 8 * (s - 28) + lrow) * p.ldb) * 4u + (unsigned)squad * 16u;
-            is_b[i] = true;
         } else {
             voff[i] = 0xfffffff0u;  // surplus slot: out of range (zeros) into the dummy area
-            is_b[i] = true;
         }
         ldst[i] = s < 32 ? (unsigned)s * 1024u : (unsigned)(FM_STAGES * FM_STAGE_BYTES);
     }
-    lds_char* const l0 = (lds_char*)fsm;
+    // The DMA is issued through inline assembly, not __builtin_amdgcn_raw_ptr_buffer_load_lds: for the builtin the compiler
+    // knows an asynchronous LDS write is in flight and, lacking alias information, puts `s_waitcnt vmcnt(0)` in front of every
+    // ds_read and every barrier -- which drains the whole ring each K-step (measured: 1.9 us per step instead of 0.5).  Here
+    // the counting is explicit: each wave issues exactly FM_SLOTS loads per step and waits with vmcnt(5 * steps in flight).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto rsrc = [](const float* ptr, unsigned bytes) __attribute__((always_inline)) {  // raw buffer descriptor: base, stride 0, size, flags
+        const uint64_t a64 = (uint64_t)(uintptr_t)ptr;
+        i32x4 d;
+        d[0] = (int)(unsigned)a64, d[1] = (int)(unsigned)((a64 >> 32) & 0xffffu), d[2] = (int)bytes, d[3] = 0x00020000;
+        return d;
+    };
+    const i32x4 qa = rsrc(p.a, (unsigned)p.m * (unsigned)p.lda * 4u), qb = rsrc(p.b, (unsigned)p.n * (unsigned)p.ldb * 4u);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)fsm;
+    // Every workgroup of a launch streams the SAME rows of A; walking K in the same order they would all ask the same few L2
+    // channels for the same lines at the same moment (rows of A are 3-12 KB apart: a K-step's 224 row segments fall on 4, or
+    // 1, of the 16 channels).  Each workgroup therefore starts its K walk at a different step (rot) and wraps around.
+    const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)steps);
     auto issue = [&](int step) __attribute__((always_inline)) {
-        const unsigned soff = (unsigned)(k_lo + step * FM_BK) * 4u;
-        lds_char* const lb = l0 + (step % FM_STAGES) * FM_STAGE_BYTES;
+        int ks = step + rot;
+        ks = ks >= steps ? ks - steps : ks;
+        const unsigned soff = (unsigned)(k_lo + ks * FM_BK) * 4u;
+        const unsigned lb = lds_base + (unsigned)(step % FM_STAGES) * FM_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < FM_SLOTS; ++i) {
-            lds_char* const dst = (wave + FM_WAVES * i < 32) ? lb + ldst[i] : l0 + ldst[i];
+            const unsigned dst = (wave + FM_WAVES * i < 32) ? lb + ldst[i] : lds_base + ldst[i];
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (is_b[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, voff[i], soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, voff[i], soff, 0, 0);
+            // slots 0..3 of a wave are always rows of A (wave + 21 <= 27), slot 4 is a row group of B (waves 0..3) or surplus
+            if (i == FM_SLOTS - 1)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[i]), "s"(qb), "s"(soff) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff[i]), "s"(qa), "s"(soff) : "memory");
 #endif
         }
     };
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(64 * FM_WAVES) void gemm_fm_kernel(const GemmFmPara
         if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F7A);       // vmcnt(10)
         else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F75);  // vmcnt(5)
         else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
-        __syncthreads();  // everybody's pieces landed; everybody finished reading the stage that step t+3 overwrites
+        __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody finished reading the stage that step t+3 overwrites
         if (t + FM_STAGES - 1 < steps) issue(t + FM_STAGES - 1);
         const int st4 = (t % FM_STAGES) * (FM_STAGE_BYTES / 16);
 #pragma unroll
@@ -178,10 +192,20 @@ __global__ __launch_bounds__(64) void reduce_ln_fwd_kernel(const float* __restri
     const int64_t row = blockIdx.x;
     float4 v[T4];
 #pragma unroll
-    for (int t = 0; t < T4; ++t) v[t] = reinterpret_cast<const float4*>(part + row * dim)[lane + 64 * t];
-    for (int s = 1; s < nsplit; ++s)
+    for (int t = 0; t < T4; ++t) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < nsplit; base += 4) {  // four slabs' loads in flight per pass (each is an L2 miss), added in order
+        float4 w[4][T4];
 #pragma unroll
-        for (int t = 0; t < T4; ++t) v[t] = add4(v[t], reinterpret_cast<const float4*>(part + s * slab + row * dim)[lane + 64 * t]);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < T4; ++t)
+                w[c][t] = base + c < nsplit ? reinterpret_cast<const float4*>(part + (base + c) * slab + row * dim)[lane + 64 * t]
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < T4; ++t) v[t] = add4(v[t], w[c][t]);
+    }
     if (bias)
 #pragma unroll
         for (int t = 0; t < T4; ++t) v[t] = add4(v[t], reinterpret_cast<const float4*>(bias)[lane + 64 * t]);
@@ -222,10 +246,20 @@ __global__ __launch_bounds__(64) void ln_bwd_part_kernel(const float* __restrict
     const int64_t row = blockIdx.x;
     float4 gg[T4], xh[T4];
 #pragma unroll
-    for (int t = 0; t < T4; ++t) gg[t] = reinterpret_cast<const float4*>(gpart + row * dim)[lane + 64 * t], xh[t] = reinterpret_cast<const float4*>(x + row * dim)[lane + 64 * t];
-    for (int s = 1; s < nsplit; ++s)
+    for (int t = 0; t < T4; ++t) gg[t] = make_float4(0.f, 0.f, 0.f, 0.f), xh[t] = reinterpret_cast<const float4*>(x + row * dim)[lane + 64 * t];
+    for (int base = 0; base < nsplit; base += 4) {
+        float4 w[4][T4];
 #pragma unroll
-        for (int t = 0; t < T4; ++t) gg[t] = add4(gg[t], reinterpret_cast<const float4*>(gpart + s * slab + row * dim)[lane + 64 * t]);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < T4; ++t)
+                w[c][t] = base + c < nsplit ? reinterpret_cast<const float4*>(gpart + (base + c) * slab + row * dim)[lane + 64 * t]
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < T4; ++t) gg[t] = add4(gg[t], w[c][t]);
+    }
     const float mu = mean[row], rs = rstd[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -244,6 +278,34 @@ __global__ __launch_bounds__(64) void ln_bwd_part_kernel(const float* __restrict
         reinterpret_cast<float4*>(gx + row * dim)[lane + 64 * t] =
             make_float4(rs * (gg[t].x - s1 - xh[t].x * s2) + ad.x, rs * (gg[t].y - s1 - xh[t].y * s2) + ad.y,
                         rs * (gg[t].z - s1 - xh[t].z * s2) + ad.z, rs * (gg[t].w - s1 - xh[t].w * s2) + ad.w);
+    }
+}
+
+// sum of split-K slabs with the QuickGELU pair / derivative (the N = 3072 GEMMs of the MLP run split too: 96 column tiles
+// alone would leave 160 CUs idle).  mode 0: h = sum + bias, g = QuickGELU(h);  mode 1: out = sum * QuickGELU'(aux).
+__global__ void reduce_gelu_kernel(const float* __restrict__ part, int nsplit, int64_t slab, const float* __restrict__ bias,
+                                   const float* __restrict__ aux, float* __restrict__ h, float* __restrict__ g, int n, int64_t total4,
+                                   int mode) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += step) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = 0; base < nsplit; base += 4) {
+            float4 w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = base + c < nsplit ? reinterpret_cast<const float4*>(part + (base + c) * slab)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = add4(v, w[c]);
+        }
+        if (mode == 0) {
+            const float4 bv = reinterpret_cast<const float4*>(bias)[q % (n >> 2)];
+            v = add4(v, bv);
+            reinterpret_cast<float4*>(h)[q] = v;
+            reinterpret_cast<float4*>(g)[q] = make_float4(quick_gelu2(v.x), quick_gelu2(v.y), quick_gelu2(v.z), quick_gelu2(v.w));
+        } else {
+            const float4 a = reinterpret_cast<const float4*>(aux)[q];
+            reinterpret_cast<float4*>(h)[q] = make_float4(v.x * quick_gelu_grad2(a.x), v.y * quick_gelu_grad2(a.y), v.z * quick_gelu_grad2(a.z),
+                                                          v.w * quick_gelu_grad2(a.w));
+        }
     }
 }
 
@@ -303,31 +365,106 @@ __device__ __forceinline__ void acc_to_lds(const f32x16& a, float* M, int i0, in
     for (int r = 0; r < 16; ++r) M[(i0 + (r & 3) + 8 * (r >> 2) + 4 * half) * AS + j0 + j] = a[r] * scale;
 }
 
-// rows [0,L) x 64 columns at column offset `col` of a [B*L, ld] matrix given as nsplit slabs (+ bias) -> LDS [64][AS], zero rows >= L
-__device__ __forceinline__ void load_head(const float* src, int nsplit, int64_t slab, const float* bias, int64_t row0, int ld, int col,
-                                          int L, float* dst) {
-    for (int e = threadIdx.x; e < AL * 16; e += 256) {
-        const int t = e >> 4, d = (e & 15) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < L) {
-            const float* q = src + (row0 + t) * ld + col + d;
-            v = *reinterpret_cast<const float4*>(q);
-            for (int s = 1; s < nsplit; ++s) v = add4(v, *reinterpret_cast<const float4*>(q + s * slab));
-            if (bias) v = add4(v, *reinterpret_cast<const float4*>(bias + col + d));
+// NH heads' worth of [L x 64] blocks (column offsets col[0..NH-1]) of a [B*L, ld] matrix given as nsplit slabs (+ bias) -> LDS
+// [64][AS] images dst[0..NH-1], zero rows >= L.  Loop order: slab outermost, the thread's 4*NH float4s inside -- 4*NH
+// independent loads in flight per slab (a per-element slab loop would chain nsplit*4*NH load latencies: measured 18 us of the
+// 22 us the kernel took).
+template <int NH, int CH>
+__device__ __forceinline__ void load_heads(const float* src, int nsplit, int64_t slab, const float* bias, int64_t row0, int ld,
+                                           const int (&col)[NH], int L, float* const (&dst)[NH]) {
+    float4 v[NH][4];
+    const int d = (threadIdx.x & 15) * 4, t0 = threadIdx.x >> 4;  // rows t0, t0+16, t0+32, t0+48
+#pragma unroll
+    for (int a = 0; a < NH; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[a][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // CH slabs per pass: all 4*NH*CH loads of a pass are issued before the first add (the slabs were written by the previous
+    // kernel on other XCDs: every load is an L2 miss of ~1-2 us, and a slab-at-a-time loop would pay that nsplit times)
+    for (int base = 0; base < nsplit; base += CH) {
+        float4 w[CH][NH][4];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int a = 0; a < NH; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = t0 + 16 * q;
+                    w[c][a][q] = (base + c < nsplit && t < L)
+                                     ? *reinterpret_cast<const float4*>(src + (base + c) * slab + (row0 + t) * ld + col[a] + d)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int a = 0; a < NH; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[a][q] = add4(v[a][q], w[c][a][q]);
+    }
+#pragma unroll
+    for (int a = 0; a < NH; ++a) {
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col[a] + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = t0 + 16 * q;
+            *reinterpret_cast<float4*>(dst[a] + t * AS + d) = t < L ? add4(v[a][q], bv) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4*>(dst + t * AS + d) = v;
     }
 }
 
-// P (pre-softmax logits in LDS) -> softmax over columns [0,L); rows >= L and columns >= L become 0.  One wave per row.
-__device__ __forceinline__ void softmax_rows(float* P, int L, int wave, int lane) {
-    for (int i = wave; i < AL; i += 4) {
-        const float x = (lane < L) ? P[i * AS + lane] : -3.0e38f;
-        const float mx = wave_max2(x);
-        const float e = (lane < L) ? __expf(x - mx) : 0.f;
-        const float sum = wave_sum2(e);
-        P[i * AS + lane] = (i < L) ? e / sum : 0.f;
+// Row-wise passes over a [64][AS] LDS matrix with FOUR ADJACENT LANES per row (thread = 4*row + quarter; quarter c owns
+// columns c, c+4, ..., c+60: conflict-free LDS access) so that the row reductions are two DPP quad permutes instead of six
+// ds_bpermute steps per reduction (one wave per row cost 5.6 us of shuffles per pass).
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += quad_xor1(v);
+    return v + quad_xor2(v);
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, quad_xor1(v));
+    return fmaxf(v, quad_xor2(v));
+}
+
+// P (logits) -> softmax over columns [0,L); rows >= L and columns >= L become 0.
+__device__ __forceinline__ void softmax_rows(float* P, int L) {
+    const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+    float x[16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int jj = 4 * u + c;
+        x[u] = jj < L ? P[i * AS + jj] : -3.0e38f;
+        mx = fmaxf(mx, x[u]);
     }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        x[u] = (4 * u + c < L) ? __expf(x[u] - mx) : 0.f;
+        sum += x[u];
+    }
+    const float inv = (i < L) ? 1.f / quad_sum(sum) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) P[i * AS + 4 * u + c] = x[u] * inv;
+}
+
+// dS = P * (dP - sum_j dP*P), in place on dS (holding dP)
+__device__ __forceinline__ void ds_rows(const float* P, float* dS) {
+    const int i = threadIdx.x >> 2, c = threadIdx.x & 3;
+    float pv[16], dv[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        pv[u] = P[i * AS + 4 * u + c], dv[u] = dS[i * AS + 4 * u + c];
+        dot += pv[u] * dv[u];
+    }
+    dot = quad_sum(dot);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dS[i * AS + 4 * u + c] = pv[u] * (dv[u] - dot);
 }
 
 __global__ __launch_bounds__(256) void attn2_fwd_kernel(const float* __restrict__ qkv, int nsplit, int64_t slab,
@@ -340,9 +477,11 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(const float* __restrict_
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, j = lane & 31;
     const int ld = 3 * H * 64;
-    load_head(qkv, nsplit, slab, bias, (int64_t)b * L, ld, h * 64, L, q);
-    load_head(qkv, nsplit, slab, bias, (int64_t)b * L, ld, (H + h) * 64, L, k);
-    load_head(qkv, nsplit, slab, bias, (int64_t)b * L, ld, (2 * H + h) * 64, L, v);
+    {
+        const int cols[3] = {h * 64, (H + h) * 64, (2 * H + h) * 64};
+        float* const dsts[3] = {q, k, v};
+        load_heads<3, 3>(qkv, nsplit, slab, bias, (int64_t)b * L, ld, cols, L, dsts);
+    }
     __syncthreads();
     const int i0 = (wave >> 1) * 32, j0 = (wave & 1) * 32;
     f32x16 acc;
@@ -350,7 +489,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(const float* __restrict_
     mm_rows_rows(acc, q, k, i0, j0, j, half);
     acc_to_lds(acc, p, i0, j0, j, half, 0.125f);
     __syncthreads();
-    softmax_rows(p, L, wave, lane);
+    softmax_rows(p, L);
     __syncthreads();
     acc_zero(acc);
     mm_rows_cols(acc, p, v, i0, j0, j, half);  // O[i][d] = sum_j P[i][j] V[j][d]
@@ -374,10 +513,14 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const float* __restrict_
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, j = lane & 31;
     const int ld = 3 * H * 64;
-    load_head(qkv, nsplit, slab, bias, (int64_t)b * L, ld, h * 64, L, q);
-    load_head(qkv, nsplit, slab, bias, (int64_t)b * L, ld, (H + h) * 64, L, k);
-    load_head(qkv, nsplit, slab, bias, (int64_t)b * L, ld, (2 * H + h) * 64, L, v);
-    load_head(gout, gsplit, gslab, nullptr, (int64_t)b * L, H * 64, h * 64, L, go);
+    {
+        const int cols[3] = {h * 64, (H + h) * 64, (2 * H + h) * 64};
+        float* const dsts[3] = {q, k, v};
+        load_heads<3, 3>(qkv, nsplit, slab, bias, (int64_t)b * L, ld, cols, L, dsts);
+        const int gcol[1] = {h * 64};
+        float* const gdst[1] = {go};
+        load_heads<1, 6>(gout, gsplit, gslab, nullptr, (int64_t)b * L, H * 64, gcol, L, gdst);
+    }
     __syncthreads();
     const int i0 = (wave >> 1) * 32, j0 = (wave & 1) * 32;
     f32x16 acc, acc2;
@@ -387,12 +530,9 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const float* __restrict_
     acc_to_lds(acc, p, i0, j0, j, half, 0.125f);
     acc_to_lds(acc2, ds, i0, j0, j, half, 1.f);
     __syncthreads();
-    softmax_rows(p, L, wave, lane);
-    for (int i = wave; i < AL; i += 4) {  // dS = P * (dP - sum_j dP*P)   (same wave as softmax_rows owns row i)
-        const float pv = p[i * AS + lane], dv = ds[i * AS + lane];
-        const float dot = wave_sum2(pv * dv);
-        ds[i * AS + lane] = pv * (dv - dot);
-    }
+    softmax_rows(p, L);
+    __syncthreads();  // (a row's four lanes wrote each other's columns)
+    ds_rows(p, ds);
     __syncthreads();
     f32x16 gq, gk, gv;
     acc_zero(gq), acc_zero(gk), acc_zero(gv);
@@ -413,6 +553,18 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const float* __restrict_
 }  // namespace w2e
 
 using namespace w2e;
+
+extern "C" int w2e_reduce_gelu(const float* part, int nsplit, int64_t slab, const float* bias, const float* aux, float* h, float* g,
+                              int64_t rows, int n, int mode, void* stream) {
+    W2E_REQUIRE(part && h && nsplit >= 1, "reduce_gelu: null tensor / bad split count");
+    W2E_REQUIRE((mode == 0 && bias && g) || (mode == 1 && aux), "reduce_gelu: mode 0 needs bias and g, mode 1 needs aux");
+    W2E_REQUIRE(rows >= 0 && n > 0 && (n & 3) == 0 && (slab & 3) == 0, "reduce_gelu: n and the slab stride must be multiples of 4");
+    const int64_t total4 = rows * n / 4;
+    if (total4 == 0) return 0;
+    reduce_gelu_kernel<<<stream_grid(total4, 256), 256, 0, (hipStream_t)stream>>>(part, nsplit, slab, bias, aux, h, g, n, total4, mode);
+    W2E_LAUNCH_CHECK("reduce_gelu");
+    return 0;
+}
 
 extern "C" int w2e_reduce_ln_fwd(const float* part, int nsplit, int64_t slab, const float* bias, const float* residual, float* x_out,
                                  const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int dim,

@@ -294,6 +294,31 @@ def _ln_bwd_part(gpart, x, gamma, mean, rstd, add):
     return gx
 
 
+def _mlp_up(y, fc_w, fc_b):
+    """h = y W_fc^T + b, g = QuickGELU(h): one launch when the shape fills the chip unsplit, else split-K + w2e_reduce_gelu."""
+    m, n = y.shape[0], fc_w.shape[0]
+    sp = _fm_splits(m, n, y.shape[1])
+    if sp == 1:
+        return _gemm_fm(y, fc_w, EPI_GELU_DUAL, bias=fc_b)
+    part = _gemm_fm(y, fc_w, EPI_PARTIAL, splits=sp)
+    h = torch.empty((m, n), device=y.device, dtype=torch.float32)
+    g = torch.empty((m, n), device=y.device, dtype=torch.float32)
+    call("w2e_reduce_gelu", ptr(part), sp, m * n, ptr(fc_b), None, ptr(h), ptr(g), m, n, 0, stream_ptr())
+    return h, g
+
+
+def _mlp_up_grad(gy, proj_wt, h):
+    """(gy W_proj) * QuickGELU'(h)."""
+    m, n = gy.shape[0], proj_wt.shape[0]
+    sp = _fm_splits(m, n, gy.shape[1])
+    if sp == 1:
+        return _gemm_fm(gy, proj_wt, EPI_GELU_GRAD, aux=h)
+    part = _gemm_fm(gy, proj_wt, EPI_PARTIAL, splits=sp)
+    out = torch.empty((m, n), device=gy.device, dtype=torch.float32)
+    call("w2e_reduce_gelu", ptr(part), sp, m * n, None, ptr(h), ptr(out), None, m, n, 1, stream_ptr())
+    return out
+
+
 class _WeightsT:
     """Transposed copies of the frozen Linear weights for the input-gradient GEMMs (gx = gy W = gy (W^T)^T: gemm_fm wants
     both operands with K contiguous).  +340 MB for ViT-B/32; rebuilt when a weight's version changes."""
@@ -332,7 +357,7 @@ class _TransformerV2(torch.autograd.Function):
             call("w2e_attn2_fwd", ptr(qkv), qkv.shape[0], m * 3 * dim, ptr(in_b), ptr(att), b, l, heads, stream_ptr())
             o = _gemm_fm(att, out_w, EPI_PARTIAL, splits=_fm_splits(m, dim, dim))
             x_mid, y2, mean2, rstd2 = _reduce_ln(o, out_b, xr, ln2_w, ln2_b, blk.ln_2.eps)
-            h, g = _gemm_fm(y2, fc_w, EPI_GELU_DUAL, bias=fc_b)
+            h, g = _mlp_up(y2, fc_w, fc_b)
             pend = _gemm_fm(g, proj_w, EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
             pbias, pres = proj_b, x_mid
             saved.append((xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h))
@@ -349,7 +374,7 @@ class _TransformerV2(torch.autograd.Function):
         g = _c(gout).reshape(m, dim)
         for blk, (xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h) in zip(reversed(ctx.blocks), reversed(ctx.saved)):
             ln1_w, _, in_w, in_b, out_w, _, ln2_w, _, fc_w, _, proj_w, _ = _block_params(blk)
-            gh = _gemm_fm(g, wt.get(proj_w), EPI_GELU_GRAD, aux=h)                       # through c_proj and QuickGELU'
+            gh = _mlp_up_grad(g, wt.get(proj_w), h)                                      # through c_proj and QuickGELU'
             gy2 = _gemm_fm(gh, wt.get(fc_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
             g_mid = _ln_bwd_part(gy2, x_mid, ln2_w, mean2, rstd2, g)                     # through ln_2, + the residual branch
             ga = _gemm_fm(g_mid, wt.get(out_w), EPI_PARTIAL, splits=_fm_splits(m, dim, dim))
