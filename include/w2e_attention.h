@@ -43,7 +43,7 @@ int w2e_cluster_accumulate(const float* feat, const int32_t* assign, float* part
  * at the kept pixels is the same distribution), nw = device scalar noise strength. */
 typedef struct {
     const float* feat;     /* [B, channels, res, res] */
-    const float* wscaled;  /* [32, channels] = conv.weight[0,:,:,0,0] / sqrt(channels) */
+    const float* wscaled;  /* [channels, 32] = (conv.weight[0,:,:,0,0] / sqrt(channels))^T: the transposed 1x1 weight */
     const float* style;    /* [B, channels] */
     const float* demod;    /* [B, 32] */
     const float* bias;     /* [32] (activate.bias) */

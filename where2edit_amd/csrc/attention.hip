@@ -13,55 +13,76 @@ __device__ __forceinline__ float wave_sum64(float v) {
 }
 
 // ---------------------------------------------------------------------------------------- cluster assignment
-// One thread per pixel, lanes along x (coalesced channel-plane reads); centroids in LDS as [dim][KP] so that the K
-// distances of one channel come from KP/4 broadcast ds_read_b128.  Distances accumulate in the reference's form
-// sum (a-b)^2 (no |a|^2 - 2ab + |b|^2 cancellation), channels in ascending order.
+// A workgroup owns 64 pixels; its 4 waves split the channel range (wave w: channels [w*C/4, (w+1)*C/4), the 2P analytic
+// position channels ride with wave 3) and the partial distances are joined through LDS in wave order -- 4x the workgroups
+// and 1/4 of the per-thread channel walk of a thread-per-pixel kernel (B*s*s = 16-32 K pixels is far too few threads for
+// 256 CUs).  Lanes run along x (coalesced channel-plane reads); centroids sit in LDS as [dim][KP] so the K distances of one
+// channel come from KP/4 broadcast ds_read_b128.  Distances accumulate in the reference's form sum (a-b)^2 (no
+// |a|^2 - 2ab + |b|^2 cancellation).
 template <int KP>
 __global__ __launch_bounds__(256) void cluster_assign_kernel(const float* __restrict__ feat, const float* __restrict__ cen,
                                                              int32_t* __restrict__ assign, int C, int P, int S, int K) {
-    extern __shared__ float lds[];  // [C + 2P][KP]
+    extern __shared__ float lds[];  // [C + 2P][KP] centroids, then [4][64][KP] partial distances
     const int D = C + 2 * P;
     for (int e = threadIdx.x; e < D * KP; e += 256) {
         const int d = e / KP, k = e % KP;
         lds[e] = k < K ? cen[(int64_t)k * D + d] : 0.f;
     }
     __syncthreads();
-    const int b = blockIdx.y;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= S * S) return;
+    float* part = lds + D * KP;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pix = blockIdx.x * 64 + lane;
+    const bool live = pix < S * S;
     float dist[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) dist[k] = 0.f;
-    const float* f = feat + (int64_t)b * C * S * S + pix;
-    for (int c = 0; c < C; ++c) {
-        const float v = f[(int64_t)c * S * S];
-        const float4* row = reinterpret_cast<const float4*>(lds + c * KP);
+    const int c_lo = (C * wave) >> 2, c_hi = (C * (wave + 1)) >> 2;
+    const float* f = feat + (int64_t)b * C * S * S + (live ? pix : 0);
+    for (int c8 = c_lo; c8 < c_hi; c8 += 8) {  // 8 channel planes' loads in flight before the first use (each is a DRAM/L2 miss)
+        float v8[8];
 #pragma unroll
-        for (int q = 0; q < KP / 4; ++q) {
-            const float4 m = row[q];
-            float t;
-            t = v - m.x, dist[4 * q + 0] += t * t;
-            t = v - m.y, dist[4 * q + 1] += t * t;
-            t = v - m.z, dist[4 * q + 2] += t * t;
-            t = v - m.w, dist[4 * q + 3] += t * t;
+        for (int u = 0; u < 8; ++u) v8[u] = (c8 + u < c_hi) ? f[(int64_t)(c8 + u) * S * S] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c8 + u >= c_hi) break;
+            const float v = v8[u];
+            const float4* row = reinterpret_cast<const float4*>(lds + (c8 + u) * KP);
+#pragma unroll
+            for (int q = 0; q < KP / 4; ++q) {
+                const float4 m = row[q];
+                float t;
+                t = v - m.x, dist[4 * q + 0] += t * t;
+                t = v - m.y, dist[4 * q + 1] += t * t;
+                t = v - m.z, dist[4 * q + 2] += t * t;
+                t = v - m.w, dist[4 * q + 3] += t * t;
+            }
         }
     }
-    const int y = pix / S, x = pix % S;
-    const float xp = (float)x * 2.f / (float)(S - 1) - 1.f, yp = (float)y * 2.f / (float)(S - 1) - 1.f;
-    for (int pc = 0; pc < 2 * P; ++pc) {
-        const float v = pc < P ? xp : yp;
-        const float* row = lds + (C + pc) * KP;
+    if (wave == 3) {
+        const int y = pix / S, x = pix % S;
+        const float xp = (float)x * 2.f / (float)(S - 1) - 1.f, yp = (float)y * 2.f / (float)(S - 1) - 1.f;
+        for (int pc = 0; pc < 2 * P; ++pc) {
+            const float v = pc < P ? xp : yp;
+            const float* row = lds + (C + pc) * KP;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const float t = v - row[k];
-            dist[k] += t * t;
+            for (int k = 0; k < KP; ++k) {
+                const float t = v - row[k];
+                dist[k] += t * t;
+            }
         }
     }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) part[(wave * 64 + lane) * KP + k] = dist[k];
+    __syncthreads();
+    if (wave != 0 || !live) return;
     int best = 0;
-    float bd = dist[0];
+    float bd = 0.f;
 #pragma unroll
-    for (int k = 1; k < KP; ++k)
-        if (k < K && dist[k] < bd) bd = dist[k], best = k;
+    for (int k = 0; k < KP; ++k) {
+        const float d = ((part[lane * KP + k] + part[(64 + lane) * KP + k]) + part[(128 + lane) * KP + k]) + part[(192 + lane) * KP + k];
+        if (k == 0) bd = d;
+        else if (k < K && d < bd) bd = d, best = k;
+    }
     assign[(int64_t)b * S * S + pix] = best;
 }
 
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(256) void att_source_kernel(const AttLaunch L) {
         __syncthreads();
         for (int e = threadIdx.x; e < cn * 32; e += 256) {
             const int i = e >> 5, o = e & 31;
-            wm[e] = s.wscaled[(int64_t)o * C + c0 + i] * s.style[(int64_t)b * C + c0 + i];
+            wm[e] = s.wscaled[(int64_t)(c0 + i) * 32 + o] * s.style[(int64_t)b * C + c0 + i];  // wscaled is [C][32]: coalesced
         }
         __syncthreads();
         if (live) {
@@ -261,9 +282,9 @@ extern "C" int w2e_cluster_assign(const float* feat, const float* centroids, int
     W2E_REQUIRE(clusters >= 1 && clusters <= 32, "cluster_assign: 1 <= clusters <= 32 (got %d)", clusters);
     if (batch == 0) return 0;
     const int kp = clusters <= 8 ? 8 : (clusters <= 16 ? 16 : 32);
-    const size_t lds = sizeof(float) * (size_t)(channels + 2 * pos_channels) * kp;
+    const size_t lds = sizeof(float) * ((size_t)(channels + 2 * pos_channels) * kp + (size_t)256 * kp);
     W2E_REQUIRE(lds <= 160 * 1024, "cluster_assign: centroids need %zu B of LDS", lds);
-    dim3 grid((unsigned)ceil_div((int64_t)size * size, 256), (unsigned)batch);
+    dim3 grid((unsigned)ceil_div((int64_t)size * size, 64), (unsigned)batch);
     hipStream_t s = (hipStream_t)stream;
     static unsigned done[3] = {0, 0, 0};
     if (kp == 8) {

@@ -173,6 +173,17 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
     def _mask_params_frozen(self):
         return not any(p.requires_grad for n, p in self.named_parameters() if n.startswith("attention") or n.startswith("initial"))
 
+    def _wscaled_t(self, conv):
+        """(scale * W[0,:,:,0,0])^T as a contiguous [C, 32] tensor, cached per conv until its weight changes."""
+        cache = self.__dict__.setdefault("_wsc_t", {})
+        w = conv.weight
+        key = (w.data_ptr(), w._version)
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = (key, (w.detach()[0, :, :, 0, 0] * conv.scale).t().contiguous())
+            cache[id(conv)] = hit
+        return hit[1]
+
     def _sources(self, n_codes):
         """(StyledConv, style EqualLinear, feature_map index) in concat order: attention_first on the const input
         (feature_map[-1], :796-802), then attention_c on feature_map[c] for the conv layers c < n_codes (:823-833)."""
@@ -198,8 +209,8 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
             if feat.shape[1] != conv.in_channel or feat.shape[2] != feat.shape[3]:
                 raise RuntimeError(f"attention source {j}: feature {tuple(feat.shape)} for a {conv.in_channel}-channel conv")
             style = aff(attention_text).contiguous()                                   # [B,C]  (:798, :826)
-            wsc = (conv.weight[0, :, :, 0, 0] * conv.scale).contiguous()               # [32,C]
-            demod = torch.rsqrt(style.square() @ wsc.square().t() + conv.eps).contiguous()  # [B,32] (model.py:244-246)
+            wsc = self._wscaled_t(conv)                                                 # [C,32] = (scale*W)^T, cached
+            demod = torch.rsqrt(style.square() @ wsc.square() + conv.eps).contiguous()  # [B,32] (model.py:244-246)
             nw = sc.noise.weight
             noise = None if self._noise_is_off(nw) else torch.randn(batch, size * size, device=dev)  # NoiseInjection, noise=None
             bias = sc.activate.bias.contiguous()
