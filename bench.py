@@ -82,6 +82,37 @@ def synthetic_latents(gen, batch, rank):
     return w.unsqueeze(1).repeat(1, gen.n_latent, 1).contiguous()
 
 
+def make_mask(coach, batch, size, rank, device, synthetic=False):
+    """The mask of BASELINE configs[2].  Default: the region-attention net's mask branch (run_attention.py:754-884) on the
+    activations of G(w) -- nearest-centroid assignment of the layer-13 features to 20 clusters, the 18 gathered 1x1 StyledConvs +
+    the 576->1 one + sigmoid, per-cluster pooling, threshold, 5x5 gaussian; random-init net and centres (no network).  Returned
+    as a callable features -> mask (Coach evaluates it between the two generator passes).  `synthetic`: a seeded U(0,1) tensor."""
+    if size == 1024 and not synthetic:
+        from where2edit_amd.run_attention import FullSpaceMapperFEATClusterLinStyle_Net, cluster_pool
+        torch.manual_seed(1)
+        att_net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
+                                                         clusters=20, cluster_dim=576).to(device).requires_grad_(False)
+        with torch.no_grad():
+            att_net.initial_bias.fill_(1.0)  # (the reference's init of 5 saturates the sigmoid: every cluster passes the threshold)
+        att_text = torch.randn(batch, 512, generator=torch.Generator().manual_seed(5 + rank)).to(device) * 0.3
+        const_in = coach.net.decoder.input.input
+
+        def mask(feats):
+            fm = list(feats) + [const_in.repeat(batch, 1, 1, 1)]
+            if not hasattr(att_net, "_seeded"):  # centres = 20 pixels of the first batch's features: non-trivial clusters
+                f = fm[12]
+                idx = torch.randperm(64 * 64, generator=torch.Generator().manual_seed(3))[:20]
+                pts = f[0].reshape(512, -1)[:, idx.to(f.device)].t()
+                ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
+                att_net.store_clusters(torch.cat([pts, xs.to(f.device)[:, None].repeat(1, 32), ys.to(f.device)[:, None].repeat(1, 32)], 1))
+            att_net._seeded = True
+            each, assign = att_net.attention_map(fm, 64, att_text, 26)
+            return cluster_pool(each, assign, 64, 20)[4]
+        return mask
+    res = 4 * 2 ** ((13 - 1) // 3) if size == 1024 else max(4, size // 16)  # seeded U(0,1) at the resolution of layer 13 (SURVEY 8d)
+    return torch.rand(batch, 1, res, res, generator=torch.Generator().manual_seed(77 + rank)).to(device)
+
+
 def pmc_traffic():
     """HBM bytes per launch of the conv kernel from the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of
     this same command, corrected as MI355X_MICROARCH.md prescribes) -- recorded in profiles/traffic.json by
@@ -216,6 +247,7 @@ def main():
                     help="the roofline's HIP events are recorded on every N-th timed step (166 timed event records per step "
                          "cost the step 5 %%: 159 images/s without them, 150 with them on every step)")
     ap.add_argument("--no-preview", action="store_true", help="skip the extra K steps in the opt-in bf16x3 conv precision (N=1 only)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the extra BASELINE configs[2] measurement of a default N=1 run")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured hipGraph (Coach.capture_step) instead of ~330 eager launches; the "
                          "per-kernel HIP-event roofline is then taken from eager steps run beside the timed region")
@@ -252,35 +284,7 @@ def main():
     _lib.set_option("conv_precision", args.conv_precision)
     coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend, args.workload)
     w = synthetic_latents(coach.net.decoder, args.batch, rank)
-    mask = None
-    if args.workload == 3:
-        if args.size == 1024 and not args.synthetic_mask:
-            # the real mask: the region-attention net's mask branch (run_attention.py:754-884) on the activations of G(w) --
-            # nearest-centroid assignment of the layer-13 features to 20 clusters, the 18 gathered 1x1 StyledConvs + the
-            # 576->1 one + sigmoid, per-cluster pooling, threshold, 5x5 gaussian.  Random-init net and centres (no network).
-            from where2edit_amd.run_attention import FullSpaceMapperFEATClusterLinStyle_Net, cluster_pool
-            torch.manual_seed(1)
-            att_net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
-                                                             clusters=20, cluster_dim=576).to(device).requires_grad_(False)
-            with torch.no_grad():
-                att_net.initial_bias.fill_(1.0)  # (the reference's init of 5 saturates the sigmoid: every cluster passes the threshold)
-            att_text = torch.randn(args.batch, 512, generator=torch.Generator().manual_seed(5 + rank)).to(device) * 0.3
-            const_in = coach.net.decoder.input.input
-
-            def mask(feats):
-                fm = list(feats) + [const_in.repeat(args.batch, 1, 1, 1)]
-                if not hasattr(att_net, "_seeded"):  # centres = 20 pixels of the first batch's features: non-trivial clusters
-                    f = fm[12]
-                    idx = torch.randperm(64 * 64, generator=torch.Generator().manual_seed(3))[:20]
-                    pts = f[0].reshape(512, -1)[:, idx.to(f.device)].t()
-                    ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
-                    att_net.store_clusters(torch.cat([pts, xs.to(f.device)[:, None].repeat(1, 32), ys.to(f.device)[:, None].repeat(1, 32)], 1))
-                att_net._seeded = True
-                each, assign = att_net.attention_map(fm, 64, att_text, 26)
-                return cluster_pool(each, assign, 64, 20)[4]
-        else:  # seeded U(0,1) mask at the resolution of layer 13
-            res = 4 * 2 ** ((13 - 1) // 3) if args.size == 1024 else max(4, args.size // 16)
-            mask = torch.rand(args.batch, 1, res, res, generator=torch.Generator().manual_seed(77 + rank)).to(device)
+    mask = make_mask(coach, args.batch, args.size, rank, device, args.synthetic_mask) if args.workload == 3 else None
 
     def barrier():
         if world > 1:
@@ -394,6 +398,27 @@ def main():
                                  "dtype": "bf16x3", "final_loss": float(last2["loss"]),
                                  "note": "opt-in --conv-precision bf16x3: each fp32 product of the 3x3 convs as three bf16 MFMA products "
                                          "(all parity tests pass with it; DESIGN.md section 7); not the headline"}
+    if world == 1 and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config3:
+        # BASELINE configs[2] in the same run, so that a driver-run line exists for it: region-attention mask (the real one) +
+        # clip_loss + id_loss (IR-SE50 on the conv engine), batch 8.  Reported beside the headline, never as `value`.
+        del coach
+        torch.cuda.empty_cache()
+        b3 = 8
+        coach3 = build_coach(args.size, b3, device, False, args.clip_backend, 3)
+        w3 = synthetic_latents(coach3.net.decoder, b3, rank)
+        mask3 = make_mask(coach3, b3, args.size, rank, device)
+        n3, ok3 = stabilise(lambda: coach3.train_step(w3, mask3))
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            last3 = coach3.train_step(w3, mask3)
+        barrier()
+        dt3 = time.perf_counter() - t3
+        out["config3"] = {"value": b3 * args.steps / dt3, "unit": "images/s", "ms_per_step": 1e3 * dt3 / args.steps, "batch": b3,
+                          "final_loss": float(last3["loss"]), "stabilise_steps": n3,
+                          "workload": "BASELINE configs[2]: FFHQ-1024 mapper step with the region-attention mask (cluster-pooled, "
+                                      "thresholded, blurred; run_attention.py:754-884) blended at layer 13 + clip_loss + id_loss "
+                                      "(IR-SE50), batch 8, 1 GPU; same as `bench.py --workload 3 --batch 8`"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     print(json.dumps(out), flush=True)

@@ -680,3 +680,39 @@ def test_generator1024_golden_with_bf16x3(w2e_opt):
     st = size // 32
     assert_close(img[:, :, ::st, ::st], g[f"g{size}.image_strided"], 1e-3, "image (north_star tolerance)")
     assert abs(img.double().abs().sum().item() / float(g[f"g{size}.image_abs_sum"]) - 1) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["same", "same_act", "same_dot", "same_split", "up", "down"])
+def test_modconv_ragged_channels_never_write_past_the_output(mode, w2e_opt):
+    """Guard band: the epilogue relies on the buffer range check to drop channels >= N when the tile is wider than
+    N (N = 40 on 64- / 128-channel tiles) and pixels outside the image.  The output lives at the head of a larger allocation
+    filled with a canary: nothing behind it (the next image's planes, in a batched tensor) may change, and the head must equal
+    the separately allocated result -- SAME (plain / fused activation / dot epilogue / split-K atomics), UP and DOWN."""
+    from where2edit_amd import functional as K
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    b, k, n, h, w = 2, 24, 40, 19, 27
+    g = torch.Generator().manual_seed(11)
+    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+    s_in, s_out = (torch.rand(b, k, generator=g) + 0.5).to(DEV), (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    pack = K.conv_pack(wt, (k * 9) ** -0.5, False, False)
+    kmode = {"up": K.MODE_UP, "down": K.MODE_DOWN}.get(mode, K.MODE_SAME)
+    x = torch.randn(b, k, 2 * h + 1, 2 * w + 1, generator=g).to(DEV) if mode == "down" else torch.randn(b, k, h, w, generator=g).to(DEV)
+    noise, nw, bias = torch.randn(1, 1, h, w, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    dw = torch.randn(b, n, h, w, generator=g).to(DEV)
+    act = (noise, nw, bias) if mode == "same_act" else None
+    dot_with = dw if mode == "same_dot" else None
+    if mode == "same_split":
+        w2e_opt("tune_cfg", "6,4,0")  # 64x64 tile, 4 K-slices: the atomic epilogue
+    ref, _ = K._modconv_raw(kmode, x, pack, s_in, s_out, h, w, act=act, dot_with=dot_with)
+    numel = ref.numel()
+    tail = 1 << 16
+    buf = torch.full((numel + tail,), 1234.5, device=DEV)
+    dot = torch.zeros(b, n, device=DEV) if dot_with is not None else None
+    call("w2e_modconv3x3", kmode, ptr(x), ptr(pack), ptr(s_in), ptr(s_out), ptr(buf), b, k, n, h, w, int(act is not None),
+         ptr(noise) if act else None, ptr(nw) if act else None, ptr(bias) if act else None, ptr(dot_with), ptr(dot), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.all(buf[numel:] == 1234.5), f"{mode}: wrote past the end of the output"
+    if mode == "up":  # the pad columns of the phase-planar rows (W+1 .. WP-1) are never written: compare the image itself
+        assert_close(K.unplanar(buf[:numel].view_as(ref), w), K.unplanar(ref, w), 1e-6, mode)
+    else:
+        assert_close(buf[:numel].view_as(ref), ref, 2e-6 if mode == "same_split" else 1e-6, mode)

@@ -33,6 +33,11 @@ class CLIPLoss(torch.nn.Module):
     def preprocess(self, image):
         """avg_pool(upsample(image)) without the 49x intermediate (clip_loss.py:15)."""
         if image.shape[-1] != self.stylegan_size or image.shape[-2] != self.stylegan_size:
+            if not getattr(self, "_warned_literal", False):
+                import warnings
+                warnings.warn(f"CLIPLoss.preprocess: image {tuple(image.shape[-2:])} is not stylegan_size {self.stylegan_size}: running the "
+                              "literal Upsample(7) -> AvgPool chain on stock ops (it materialises the 49x image)")
+                self._warned_literal = True
             return self.avg_pool(self.upsample(image))  # sizes the closed form does not cover: literal chain
         return K.clip_preprocess(image)
 
