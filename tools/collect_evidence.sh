@@ -26,7 +26,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats3 -o stats --outpu
 cp $(find $R/stats3 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_w3_b8.csv
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats_w3_b8.csv $(python3 -c "import json;d=json.loads([l for l in open('$O/bench_stats_w3.log') if l.startswith('{')][-1]);print(d['steps']+d['warmup']+d['config']['stabilise_steps'])") > $O/kernel_stats_w3_b8_summary.txt
 echo stats3 done
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $(find $R/fetch -name '*counter_collection.csv' | head -1) $(find $R/write -name '*counter_collection.csv' | head -1) $TAG $O > $O/pmc.log 2>&1 || true
 echo pmc done

@@ -157,7 +157,7 @@ class Coach:
         return loss_dict
 
     # ---- the fixed-shape step as ONE hipGraph launch -------------------------------------------------------------
-    def capture_step(self, w, mask=None, warmup=3):
+    def capture_step(self, w, mask=None, warmup=3, side_stream=False):
         """Capture zero-grad + forward_pair + calc_loss + backward for inputs of w's shape into a hipGraph (about 330
         kernel / memset nodes at 1024^2) and return `step(w[, mask]) -> loss_dict`, which copies the inputs into the
         graph's static buffers, replays it, then runs the gradient all-reduce and the optimizer eagerly (Ranger's
@@ -167,6 +167,12 @@ class Coach:
         from . import profiling
         if profiling._active is not None:
             raise RuntimeError("capture_step: per-kernel HIP-event timing cannot be recorded inside a graph")
+        # `side_stream`: inside the graph the no-grad G(w) pass forks onto a second stream (its large conv launches fill the CUs
+        # that the launch-bound parts of the main branch leave idle: +1-2 % images/s); eager steps keep one stream, so that
+        # per-kernel HIP-event durations are not stretched by overlap
+        eager_side = self._side
+        if side_stream and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
         if callable(mask):
             raise RuntimeError("capture_step: pass the mask tensor (a callable mask is evaluated eagerly)")
         s_space = getattr(self.opts, "work_in_stylespace", False)
@@ -196,8 +202,11 @@ class Coach:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = body()
+        try:
+            with torch.cuda.graph(graph):
+                static_out = body()
+        finally:
+            self._side = eager_side
 
         def step(w_new, mask_new=None):
             if s_space:
