@@ -102,3 +102,35 @@ def test_ranger_matches_reference_fixture():
     assert set(st) == {"step", "exp_avg", "exp_avg_sq", "slow_buffer"} and st["step"] == 13
     with pytest.raises(ValueError):
         Ranger(params, lr=0.0)
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from where2edit_amd import dist as wd
+    from where2edit_amd.run_attention import GatherLayer, info_nce
+    wd.init_from_env(backend="gloo")
+    img = wd.shard(seeded.tensor("nce.img", (6, 32)), rank, world).clone().requires_grad_(True)
+    txt = wd.shard(seeded.tensor("nce.txt", (6, 32)), rank, world).clone()
+    gathered = torch.cat(GatherLayer.apply(img), 0)
+    loss = info_nce(img, txt)  # gathers both sets over the ranks itself (run_attention.py:1312-1318)
+    loss.backward()
+    torch.save({"gathered": gathered.detach(), "loss": loss.detach(), "grad": img.grad.clone()}, os.path.join(out_dir, f"nce{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gather_layer_and_infonce_over_two_ranks(tmp_path):
+    """utils.py:114-131 GatherLayer + the InfoNCE term of the region-attention loop on 2 gloo ranks: every rank sees the
+    global batch, the loss equals the single-process full-batch loss, and the backward keeps exactly this rank's rows of the
+    full-batch gradient (GatherLayer.backward takes grads[rank], no reduction -- so each rank holds d(loss)/d(its rows))."""
+    from oracle import attention_net as OA
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"nce{r}.pt") for r in range(world)]
+    img = seeded.tensor("nce.img", (6, 32)).requires_grad_(True)
+    txt = seeded.tensor("nce.txt", (6, 32))
+    full = OA.info_nce(img, txt)
+    full.backward()
+    for r in range(world):
+        assert torch.equal(res[r]["gathered"], img.detach())
+        assert_close(res[r]["loss"], full.detach(), 1e-6, "InfoNCE over the gathered batch")
+        assert_close(res[r]["grad"], img.grad[r * 3:(r + 1) * 3], 1e-5, "this rank's rows of the full-batch gradient")
