@@ -247,12 +247,16 @@ def main():
                     help="the roofline's HIP events are recorded on every N-th timed step (166 timed event records per step "
                          "cost the step 5 %%: 159 images/s without them, 150 with them on every step)")
     ap.add_argument("--no-preview", action="store_true", help="skip the extra K steps in the opt-in bf16x3 conv precision (N=1 only)")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="inside the graph, fork the no-grad G(w) pass onto a second stream (+1-2 %% images/s; off by default: "
+                         "overlapped kernels stretch each other's durations, so a rocprofv3 trace of the run would no longer "
+                         "show the per-kernel times the roofline is quoted on)")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra BASELINE configs[2] measurement of a default N=1 run")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
-                    help="replay the step as one captured hipGraph (Coach.capture_step, the no-grad G(w) pass forked onto a second "
-                         "stream inside it) instead of ~330 eager launches; the per-kernel HIP-event roofline is then taken from "
-                         "eager single-stream steps run right after the timed region.  auto (default): graph when the capture "
-                         "succeeds and the mask is a tensor, else eager; off: eager")
+                    help="replay the step as one captured hipGraph (Coach.capture_step) instead of ~330 eager launches; the per-kernel "
+                         "HIP-event roofline is then taken from eager steps run right after the timed region (same kernels, same "
+                         "stream order).  auto (default): graph when the capture succeeds and the mask is a tensor, else eager; "
+                         "off: eager")
     ap.add_argument("--synthetic-mask", action="store_true", help="workload 3: a seeded U(0,1) mask instead of the region-attention net's")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank; default) or gloo (self-test: the ranks may share a GPU)")
@@ -302,7 +306,7 @@ def main():
             graph_note = "eager: callable mask"
         else:
             try:
-                graphed = coach.capture_step(w, mask, side_stream=True)
+                graphed = coach.capture_step(w, mask, side_stream=args.side_stream)
                 step_fn = lambda: graphed(w, mask)  # noqa: E731
                 use_graph = True
             except Exception as e:  # noqa: BLE001  (any capture failure: measure eagerly rather than not at all)
@@ -368,7 +372,7 @@ def main():
                                 f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
                    "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
-                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "dist_backend": args.dist_backend if world > 1 else None},
+                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None},
     }
     if timer is not None:
         s = timer.summary()

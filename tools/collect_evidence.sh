@@ -20,11 +20,11 @@ echo micro done
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats -o stats --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-preview --no-config3 --no-cpu-baseline > $O/bench_stats.log 2>&1
 cp $(find $R/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
-python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats.csv $(python3 -c "import json;d=json.loads([l for l in open('$O/bench_stats.log') if l.startswith('{')][-1]);print(d['steps']+d['warmup']+d['config']['stabilise_steps'])") > $O/kernel_stats_summary.txt
+python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats.csv auto > $O/kernel_stats_summary.txt
 echo stats done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats3 -o stats --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload 3 --batch 8 --steps 10 --warmup 3 --no-preview --no-config3 --no-cpu-baseline > $O/bench_stats_w3.log 2>&1
 cp $(find $R/stats3 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_w3_b8.csv
-python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats_w3_b8.csv $(python3 -c "import json;d=json.loads([l for l in open('$O/bench_stats_w3.log') if l.startswith('{')][-1]);print(d['steps']+d['warmup']+d['config']['stabilise_steps'])") > $O/kernel_stats_w3_b8_summary.txt
+python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats_w3_b8.csv auto > $O/kernel_stats_w3_b8_summary.txt
 echo stats3 done
 timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
 timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
