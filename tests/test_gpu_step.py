@@ -495,3 +495,28 @@ def test_graphed_step_equals_eager_step():
         assert graphed.global_step == 7
     finally:
         where2edit_amd.set_deterministic(False)
+
+
+def test_merged_forward_equals_two_passes():
+    """Coach.forward_pair runs x = G(w) and x_hat = G(w_hat) as one generator pass over [w; w_hat], with the backward of every
+    generator node restricted to the w_hat rows (functional.nograd_prefix).  Same images, losses and mapper gradients as the
+    reference's two separate passes (merge_forward = False), at 64^2 and -- the tile choices depend on the batch -- at 1024^2."""
+    import bench
+    for build in (lambda: _coach(_opts())[0], lambda: bench.build_coach(1024, 2, DEV, False, "hip", 2)):
+        merged, split = build(), build()
+        split.merge_forward = False
+        assert merged.merge_forward
+        size = merged.opts.stylegan_size
+        w = (seeded.wplus_latents(2, OG.n_latent(size), salt=77).to(DEV) if size == SIZE else bench.synthetic_latents(merged.net.decoder, 2, 0))
+        outs = []
+        for c in (merged, split):
+            c.optimizer.zero_grad()
+            x, x_hat, w_hat = c.forward_pair(w)
+            loss, _ = c.calc_loss(w, x, w_hat, x_hat)
+            loss.backward()
+            outs.append((x, x_hat, w_hat, loss.detach(), torch.cat([p.grad.reshape(-1) for p in c.net.mapper.parameters()])))
+        a, b = outs
+        assert a[0].shape == b[0].shape and not a[0].requires_grad
+        assert_close(a[0], b[0], 1e-5, "x"), assert_close(a[1], b[1], 1e-5, "x_hat"), assert_close(a[2], b[2], 1e-6, "w_hat")
+        assert abs(float(a[3]) - float(b[3])) <= 1e-5 * abs(float(b[3]))
+        assert_grad_close(a[4], b[4], "mapper gradients, merged vs two passes", tol=2e-3)

@@ -55,6 +55,8 @@ class Coach:
         # Off by default: overlapped kernels stretch each other's durations, which blurs per-kernel roofline numbers.
         self._side = torch.cuda.Stream(device=self.device) if os.environ.get("W2E_SIDE_STREAM", "0") == "1" else None
         self._side_primed = False
+        # one merged generator pass for x and x_hat (forward_pair); W2E_MERGE_FORWARD=0 keeps the reference's two passes
+        self.merge_forward = os.environ.get("W2E_MERGE_FORWARD", "1") != "0"
 
     def configure_optimizers(self):
         params = list(self.net.mapper.parameters())  # mapper only: the decoder is never optimised (coach.py:174-180)
@@ -87,6 +89,19 @@ class Coach:
             x_hat, w_hat, _ = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False, truncation=1,
                                   attention_layer=att_layer, attention_map=mask, feature_map=feats)
             return x, x_hat, w_hat
+        if self.merge_forward and self._side is None and not s_space and torch.is_grad_enabled():
+            # x = G(w) (no grad) and x_hat = G(w_hat) as ONE generator pass over [w; w_hat]: twice the rows per launch (the
+            # same kernels run ~9 % faster per image at twice the batch) and half the forward launches.  Values are the ones of
+            # the two separate passes (per-sample arithmetic); the backward of every generator node works on the w_hat rows
+            # only (functional.nograd_prefix), so no gradient work is spent on the no-grad half.
+            from . import functional as K
+            n = w.shape[0]
+            w_hat = w + 0.1 * self.net.mapper(w)
+            with K.nograd_prefix(n):
+                both, lat, _ = dec([torch.cat([w.detach(), w_hat])], input_is_latent=True, return_latents=True, randomize_noise=False,
+                                   truncation=1)
+            self._x_ready = None
+            return both[:n].detach(), both[n:], lat[n:]
         main = torch.cuda.current_stream()
         if self._side is not None and not self._side_primed:
             # the decoder's derived-weight caches (conv packs, wsq, stacked affines) are built lazily by the first pass:
