@@ -241,7 +241,7 @@ def test_bench_workload2_step_matches_oracle(capfd):
     the full ViT-B/32 critic, random-init weights with the bench's noise-strength / bias perturbation, the bench's
     synthetic latents -- against oracle.step.mapper_step_loss on the same state_dicts: x, x_hat, the loss terms and the
     mapper gradients.  Also records which conv tile / split-K the library picks for every launch of that step
-    (gpurun_out/bench_cfg_selections.txt; the selection depends on the batch)."""
+    (gpurun_out/bench_cfg_selections.txt; the selection depends on the batch: the merged forward runs at batch 8, the backward at 4)."""
     import bench
     from where2edit_amd import _lib
     size, batch = 1024, 4
@@ -269,7 +269,8 @@ def test_bench_workload2_step_matches_oracle(capfd):
         _lib.set_option("tune_print", 0)
     sel = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("modconv mode") or ln.startswith("  ")]
     n_conv = sum(ln.startswith("modconv mode") for ln in sel)
-    assert n_conv == 51, n_conv  # 2 x 17 forward launches + 17 input-gradient launches per step at 1024^2
+    # 17 forward launches over the merged batch [w; w_hat] (batch 8) + 17 input-gradient launches over the w_hat rows (batch 4)
+    assert n_conv == 34, n_conv
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "bench_cfg_selections.txt"), "w") as f:
