@@ -231,6 +231,66 @@ def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0):
     return len(times), False
 
 
+def bench_config5(args, rank, world, device):
+    """BASELINE configs[4] on this rank's share of the images: 256^2 image -> e4e -> S codes -> features -> region-attention
+    net (mask + new codes) -> masked 1024^2 generator -> CLIP features (where2edit_amd.demo_pipeline.invert_and_edit).
+    Inference: every rank works on its own images, nothing is exchanged.  Random-init weights of the real architectures."""
+    from where2edit_amd.attention_model import Generator
+    from where2edit_amd.clip_loss import CLIPLoss
+    from where2edit_amd.clip_vit import CLIP
+    from where2edit_amd.demo_pipeline import invert_and_edit
+    from where2edit_amd.psp_encoders import Encoder4Editing
+    from where2edit_amd.run_attention import FullSpaceMapperFEATClusterLinStyle_Net
+    torch.manual_seed(0)
+    opts = types.SimpleNamespace(stylegan_size=1024)
+    g = Generator(1024, 512, 8).to(device).eval().requires_grad_(False)
+    e4e = Encoder4Editing(50, "ir_se", opts).to(device).eval().requires_grad_(False)
+    clip = CLIPLoss(opts, model=CLIP(visual_backend=args.clip_backend)).to(device)
+    net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
+                                                 clusters=20, cluster_dim=576).to(device).eval().requires_grad_(False)
+    with torch.no_grad():
+        net.initial_bias.fill_(1.0)
+    gen = torch.Generator().manual_seed(100 + rank)
+    imgs = (torch.rand(args.batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+    text, att = (torch.randn(args.batch, 512, generator=gen) * 0.3).to(device), (torch.randn(args.batch, 512, generator=gen) * 0.3).to(device)
+
+    def step():
+        return invert_and_edit(imgs, e4e, g, clip, net, text, att, attention_layer=13)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    n_stab, ok = stabilise(step)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
+    finite = bool(torch.isfinite(out["img_gen"]).all())
+    if not finite:
+        raise SystemExit("non-finite output")
+    print(json.dumps({
+        "metric": "1024^2 edited images/sec, invert-and-edit inference pipeline (BASELINE configs[4])", "value": args.batch * world * args.steps / dt,
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"e4e encode -> S codes -> 26 features -> region-attention net (cluster-pooled mask, new codes) -> masked "
+                               f"FFHQ-1024 generator -> CLIP features (show_demo/try_demo.py:93-157), batch {args.batch}/GPU, no backward",
+                   "global_batch": args.batch * world, "parallelism": f"replicas x{world}", "stabilise_steps": n_stab, "stabilised": ok,
+                   "mask_mean": float(out["mask"].mean())}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,9 +325,11 @@ def main():
                     help="f32 (default): exact fp32 MFMA everywhere.  bf16x3: the SAME-resolution and up-sampling conv tiles compute each fp32 "
                          "product as three bf16 products (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product; every "
                          "parity test passes with it) -- opt-in, reported as dtype bf16x3")
-    ap.add_argument("--workload", type=int, default=2, choices=[2, 3],
+    ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE configs index + 1: 2 = clip_loss mapper step (the headline, default); 3 = the same step with "
-                         "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8)")
+                         "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8); 5 = the inference pipeline "
+                         "e4e encode -> cluster-pooled mask -> mapper edit -> 1024^2 generator (show_demo/try_demo.py:93-157; "
+                         "replicas only at N > 1, no collective)")
     args = ap.parse_args()
     tune = sorted(k for k in os.environ if k.startswith("W2E_TUNE_"))
     if tune:  # the tuning aids can skip work or force slow tiles: never measure with them set
@@ -288,6 +350,8 @@ def main():
     device = f"cuda:{local % max(n_dev, 1)}"
     torch.cuda.set_device(device)
     _lib.set_option("conv_precision", args.conv_precision)
+    if args.workload == 5:
+        return bench_config5(args, rank, world, device)
     coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend, args.workload)
     w = synthetic_latents(coach.net.decoder, args.batch, rank)
     mask = make_mask(coach, args.batch, args.size, rank, device, args.synthetic_mask) if args.workload == 3 else None
