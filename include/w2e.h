@@ -145,6 +145,14 @@ int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx,
  * this kernel.  gx_acc NULL = w2e_torgb_bwd. */
 int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float* gy, const float* gx_acc, float* gx, float* gwmod,
                       int batch, int cin, int h, int w, void* stream);
+/* The same pair with the modulation formed in the kernel (model.py:239 with k = 1, demodulate=False): wsc [3,cin] =
+ * scale*W shared by the batch, style [B,cin]; the weight of sample b is wsc[c,i]*style[b,i].  The backward writes the
+ * STYLE gradient gstyle[b,i] = sum_c wsc[c,i] * sum_p x[b,i,p]*gy[b,c,p] ([B,cin]; W is frozen on this path) and
+ * gx as w2e_torgb_bwd_acc (gx_acc may be NULL). */
+int w2e_torgb_styled_fwd(const float* x, const float* wsc, const float* style, const float* bias, const float* skip,
+                         const float* upk, float* y, int batch, int cin, int h, int w, void* stream);
+int w2e_torgb_styled_bwd(const float* x, const float* wsc, const float* style, const float* gy, const float* gx_acc,
+                         float* gx, float* gstyle, int batch, int cin, int h, int w, void* stream);
 
 /* ---- K5  CLIP preprocessing  (criteria/clip_loss.py:11-12,15) ------------------------------
  * AvgPool2d(size/32)(Upsample(x7, nearest)(img)) in closed form: [planes,size,size] -> [planes,224,224];

@@ -594,6 +594,39 @@ def test_to_rgb_passthrough_joins_gradients(cin, h, with_skip):
         assert_close(a, bb, 1e-6, name)
 
 
+@pytest.mark.parametrize("cin,h,with_skip,prefix", [(32, 64, True, 0), (12, 18, False, 0), (512, 8, True, 1), (64, 128, True, 2)])
+def test_to_rgb_styled_equals_per_sample_weight(cin, h, with_skip, prefix):
+    """w2e_torgb_styled_*: the kernels form scale*W[c,i]*style[b,i] themselves and return the style gradient; same image and
+    the same gradients as the [B,3,cin] per-sample weight built by an elementwise product (model.py:239 with k = 1), also
+    with the rows of a no-grad prefix skipped (functional.nograd_prefix: their gradient rows are zero / never read)."""
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(7 * cin + h)
+    b = 4
+    k4 = cu(seeded.fir_kernel(gain=4.0))
+    x0, wsc, st0 = torch.randn(b, cin, h, h, generator=g), (torch.randn(3, cin, generator=g) * 0.2).to(DEV), torch.randn(b, cin, generator=g)
+    bias = torch.randn(1, 3, 1, 1, generator=g).to(DEV)
+    skip0 = torch.randn(b, 3, h // 2, h // 2, generator=g) if with_skip else None
+    r = torch.randn(b, 3, h, h, generator=g).to(DEV)
+
+    def run(styled):
+        x, st = x0.to(DEV).requires_grad_(True), st0.to(DEV).requires_grad_(True)
+        skip = skip0.to(DEV).requires_grad_(True) if with_skip else None
+        with K.nograd_prefix(prefix):
+            if styled:
+                y = K.to_rgb(x, wsc, bias, skip, k4 if with_skip else None, style=st)
+            else:
+                y = K.to_rgb(x, wsc.view(1, 3, cin) * st.view(b, 1, cin), bias, skip, k4 if with_skip else None)
+        grads = torch.autograd.grad((y[prefix:] * r[prefix:]).sum(), [x, st] + ([skip] if with_skip else []))
+        return y.detach(), [t[prefix:] for t in grads], grads[1][:prefix]
+
+    y_a, g_a, head = run(True)
+    y_b, g_b, _ = run(False)
+    assert torch.equal(y_a, y_b)
+    assert not head.any()
+    for a, bb, name in zip(g_a, g_b, ["gx", "gstyle", "gskip"]):
+        assert_close(a, bb, 2e-6, name)
+
+
 @pytest.mark.parametrize("b,k,n,h,w,cfg", [(2, 20, 40, 37, 53, 0), (1, 8, 8, 70, 33, 1), (2, 33, 130, 16, 100, 2), (1, 24, 32, 40, 64, 8),
                                             (1, 256, 256, 64, 64, 0)])
 def test_modconv_bf16x3_split_precision(b, k, n, h, w, cfg, w2e_opt):

@@ -199,11 +199,8 @@ class Coach:
             if self.bucket is not None:
                 self.bucket.zero()
             else:
-                for p in params:  # static .grad tensors, zeroed in place: the graph's nodes keep pointing at them
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    else:
-                        p.grad.zero_()
+                for p in params:  # no zero fill + accumulate per parameter: the backward's own gradient tensors (static
+                    p.grad = None  # addresses in the graph's memory pool) become the .grad of every replay
             x, x_hat, w_hat = self.forward_pair(static_w, static_mask)
             loss, loss_dict = self.calc_loss(static_w, x, w_hat, x_hat)
             loss.backward()
@@ -222,6 +219,7 @@ class Coach:
                 static_out = body()
         finally:
             self._side = eager_side
+        static_grads = [p.grad for p in params]
 
         def step(w_new, mask_new=None):
             if s_space:
@@ -234,6 +232,9 @@ class Coach:
             graph.replay()
             if self.bucket is not None:
                 self.bucket.all_reduce_mean()
+            else:  # an eager step in between (optimizer.zero_grad()) may have detached them
+                for p, g in zip(params, static_grads):
+                    p.grad = g
             self.optimizer.step()
             self.global_step += 1
             return static_out

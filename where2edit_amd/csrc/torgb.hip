@@ -8,8 +8,11 @@ namespace w2e {
 
 // y[b,c,p] = sum_i wmod[b,c,i] * x[b,i,p] + bias[c] + up2(skip)[b,c,p]
 // Block = PQ pixel groups x CG channel groups (PQ*CG = 256); V pixels per thread (4 = float4).
+// `style` != null: wmod is the shared [3][cin] scale*W and the per-sample weight wmod[c,i]*style[b,i] is formed here
+// (model.py:239 with k = 1) instead of by a [B,3,cin] elementwise launch.
 template <int CG, int V>
 __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wmod,
+                                                        const float* __restrict__ style,
                                                         const float* __restrict__ bias, const float* __restrict__ skip,
                                                         const float* __restrict__ upk, float* __restrict__ y, int cin,
                                                         int H, int W) {
@@ -20,7 +23,14 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     __shared__ float kf[16];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int64_t HW = (int64_t)H * W;
-    for (int i = tid; i < 3 * cin; i += 256) wsm[i] = wmod[(int64_t)b * 3 * cin + i];
+    if (style) {
+        for (int i = tid; i < cin; i += 256) {
+            const float st = style[(int64_t)b * cin + i];
+            wsm[i] = wmod[i] * st, wsm[cin + i] = wmod[cin + i] * st, wsm[2 * cin + i] = wmod[2 * cin + i] * st;
+        }
+    } else {
+        for (int i = tid; i < 3 * cin; i += 256) wsm[i] = wmod[(int64_t)b * 3 * cin + i];
+    }
     if (tid < 16 && skip) kf[tid] = upk[15 - tid];  // flipped: true convolution (op/upfirdn2d.py:47)
     __syncthreads();
     const int cg = tid / PQ, pq = tid % PQ;
@@ -104,8 +114,10 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // gwmod[b,c,i] (+)= sum_p x[b,i,p]*gy[b,c,p].  The 4 waves of a block take 4 consecutive channels of the
 // same pixel range so their gy reads share L1.  ACC: gx = gx_acc + (that sum) -- the gradient that reached x through its
 // other consumer (the next conv) is folded in here instead of by a separate elementwise add of two activation-sized tensors.
+// `style` != null (see the forward): wmod is [3][cin] and gwmod is the STYLE gradient [B][cin] = sum_c wmod[c,i]*(that sum).
 template <int V, bool ACC>
 __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wmod,
+                                                        const float* __restrict__ style,
                                                         const float* __restrict__ gy, const float* __restrict__ gx_acc,
                                                         float* __restrict__ gx, float* __restrict__ gwmod, int cin,
                                                         int64_t HW, int splits, int64_t per_split) {
@@ -114,8 +126,14 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
     const int i = (blockIdx.x / splits) * 4 + wave;
     const int b = blockIdx.y;
     if (i >= cin) return;
-    const float w0 = wmod[((int64_t)b * 3 + 0) * cin + i], w1 = wmod[((int64_t)b * 3 + 1) * cin + i],
-                w2 = wmod[((int64_t)b * 3 + 2) * cin + i];
+    float w0, w1, w2;
+    if (style) {
+        const float st = style[(int64_t)b * cin + i];
+        w0 = wmod[i] * st, w1 = wmod[cin + i] * st, w2 = wmod[2 * cin + i] * st;
+    } else {
+        w0 = wmod[((int64_t)b * 3 + 0) * cin + i], w1 = wmod[((int64_t)b * 3 + 1) * cin + i],
+        w2 = wmod[((int64_t)b * 3 + 2) * cin + i];
+    }
     const float* xp = x + ((int64_t)b * cin + i) * HW;
     float* gp = gx + ((int64_t)b * cin + i) * HW;
     const float* ap = ACC ? gx_acc + ((int64_t)b * cin + i) * HW : nullptr;
@@ -152,9 +170,16 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
     }
     s0 = wave_sum64(s0), s1 = wave_sum64(s1), s2 = wave_sum64(s2);
     if (lane == 0) {
-        float* d = gwmod + (int64_t)b * 3 * cin + i;
-        if (splits == 1) d[0] = s0, d[cin] = s1, d[2 * cin] = s2;
-        else atomicAdd(d, s0), atomicAdd(d + cin, s1), atomicAdd(d + 2 * cin, s2);
+        if (style) {
+            const float g = wmod[i] * s0 + wmod[cin + i] * s1 + wmod[2 * cin + i] * s2;
+            float* d = gwmod + (int64_t)b * cin + i;
+            if (splits == 1) d[0] = g;
+            else atomicAdd(d, g);
+        } else {
+            float* d = gwmod + (int64_t)b * 3 * cin + i;
+            if (splits == 1) d[0] = s0, d[cin] = s1, d[2 * cin] = s2;
+            else atomicAdd(d, s0), atomicAdd(d + cin, s1), atomicAdd(d + 2 * cin, s2);
+        }
     }
 }
 
@@ -162,8 +187,8 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
 
 using namespace w2e;
 
-extern "C" int w2e_torgb_fwd(const float* x, const float* wmod, const float* bias, const float* skip, const float* upk,
-                             float* y, int batch, int cin, int h, int w, void* stream) {
+static int torgb_fwd_impl(const float* x, const float* wmod, const float* style, const float* bias, const float* skip,
+                          const float* upk, float* y, int batch, int cin, int h, int w, void* stream) {
     W2E_REQUIRE(x && wmod && y, "torgb_fwd: null tensor");
     W2E_REQUIRE(batch >= 0 && cin > 0 && h > 0 && w > 0, "torgb_fwd: bad dims");
     W2E_REQUIRE(!skip || (upk && (h % 2 == 0) && (w % 2 == 0)), "torgb_fwd: skip needs the 4x4 kernel and even h,w");
@@ -179,7 +204,7 @@ extern "C" int w2e_torgb_fwd(const float* x, const float* wmod, const float* bia
     const int pq = 256 / cg;
     dim3 grid((unsigned)ceil_div(groups, pq), (unsigned)batch);
     const size_t lds = sizeof(float) * ((size_t)3 * cin + (cg > 1 ? (size_t)256 * 3 * v : 0));
-#define W2E_TORGB(CG, V) torgb_fwd_kernel<CG, V><<<grid, 256, lds, s>>>(x, wmod, bias, skip, upk, y, cin, h, w)
+#define W2E_TORGB(CG, V) torgb_fwd_kernel<CG, V><<<grid, 256, lds, s>>>(x, wmod, style, bias, skip, upk, y, cin, h, w)
     if (vec) {
         if (cg == 1) W2E_TORGB(1, 4);
         else if (cg == 4) W2E_TORGB(4, 4);
@@ -194,13 +219,39 @@ extern "C" int w2e_torgb_fwd(const float* x, const float* wmod, const float* bia
     return 0;
 }
 
+extern "C" int w2e_torgb_fwd(const float* x, const float* wmod, const float* bias, const float* skip, const float* upk,
+                             float* y, int batch, int cin, int h, int w, void* stream) {
+    return torgb_fwd_impl(x, wmod, nullptr, bias, skip, upk, y, batch, cin, h, w, stream);
+}
+
+extern "C" int w2e_torgb_styled_fwd(const float* x, const float* wsc, const float* style, const float* bias, const float* skip,
+                                    const float* upk, float* y, int batch, int cin, int h, int w, void* stream) {
+    W2E_REQUIRE(style, "torgb_styled_fwd: null style");
+    return torgb_fwd_impl(x, wsc, style, bias, skip, upk, y, batch, cin, h, w, stream);
+}
+
+static int torgb_bwd_impl(const float* x, const float* wmod, const float* style, const float* gy, const float* gx_acc,
+                          float* gx, float* gwmod, int batch, int cin, int h, int w, void* stream);
+
 extern "C" int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx, float* gwmod, int batch,
                              int cin, int h, int w, void* stream) {
-    return w2e_torgb_bwd_acc(x, wmod, gy, nullptr, gx, gwmod, batch, cin, h, w, stream);
+    return torgb_bwd_impl(x, wmod, nullptr, gy, nullptr, gx, gwmod, batch, cin, h, w, stream);
 }
 
 extern "C" int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float* gy, const float* gx_acc, float* gx,
                                  float* gwmod, int batch, int cin, int h, int w, void* stream) {
+    return torgb_bwd_impl(x, wmod, nullptr, gy, gx_acc, gx, gwmod, batch, cin, h, w, stream);
+}
+
+extern "C" int w2e_torgb_styled_bwd(const float* x, const float* wsc, const float* style, const float* gy,
+                                    const float* gx_acc, float* gx, float* gstyle, int batch, int cin, int h, int w,
+                                    void* stream) {
+    W2E_REQUIRE(style, "torgb_styled_bwd: null style");
+    return torgb_bwd_impl(x, wsc, style, gy, gx_acc, gx, gstyle, batch, cin, h, w, stream);
+}
+
+static int torgb_bwd_impl(const float* x, const float* wmod, const float* style, const float* gy, const float* gx_acc,
+                          float* gx, float* gwmod, int batch, int cin, int h, int w, void* stream) {
     W2E_REQUIRE(x && wmod && gy && gx && gwmod, "torgb_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && cin > 0 && h > 0 && w > 0, "torgb_bwd: bad dims");
     W2E_REQUIRE(batch < 65536, "torgb_bwd: batch too large");
@@ -217,17 +268,17 @@ extern "C" int w2e_torgb_bwd_acc(const float* x, const float* wmod, const float*
     int64_t per_split = ceil_div(hw, splits);
     per_split = (per_split + 255) & ~int64_t(255);
     splits = (int)ceil_div(hw, per_split);
-    if (splits > 1 && zero_async(gwmod, sizeof(float) * 3 * (size_t)batch * cin, s) != hipSuccess) {
+    if (splits > 1 && zero_async(gwmod, sizeof(float) * (style ? 1 : 3) * (size_t)batch * cin, s) != hipSuccess) {
         set_error("torgb_bwd: memset failed");
         return 2;
     }
     dim3 grid((unsigned)(ceil_div(cin, 4) * splits), (unsigned)batch);
     if ((hw & 3) == 0) {
-        if (gx_acc) torgb_bwd_kernel<4, true><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
-        else torgb_bwd_kernel<4, false><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        if (gx_acc) torgb_bwd_kernel<4, true><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        else torgb_bwd_kernel<4, false><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
     } else {
-        if (gx_acc) torgb_bwd_kernel<1, true><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
-        else torgb_bwd_kernel<1, false><<<grid, 256, 0, s>>>(x, wmod, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        if (gx_acc) torgb_bwd_kernel<1, true><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        else torgb_bwd_kernel<1, false><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
     }
     W2E_LAUNCH_CHECK("torgb_bwd");
     return 0;

@@ -36,9 +36,11 @@ class nograd_prefix:
         _NOGRAD_PREFIX = self.prev
 
 
-def _pad_rows(t, n):
-    """[B-n, ...] -> [B, ...] with zero rows in front ([B,C]-sized tensors only)."""
-    return t if n == 0 else torch.cat([t.new_zeros((n,) + tuple(t.shape[1:])), t])
+def _zeros_with_tail(full, n, tail_shape, device):
+    """-> (buf, tail): a zeroed [full, *tail_shape] fp32 buffer and its rows [n:] (a contiguous view) for a kernel to write:
+    the [B,C]-sized gradients of a node inside `nograd_prefix` in one fill, no concatenation."""
+    buf = torch.zeros((full,) + tuple(tail_shape), device=device, dtype=torch.float32)
+    return buf, (buf[n:] if n else buf)
 
 
 def _c(t):
@@ -46,13 +48,14 @@ def _c(t):
 
 
 # ------------------------------------------------------------------------------------------ K2
-def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=None, planar_hw=None):
+def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=None, planar_hw=None, out=None):
     """One launch of w2e_upfirdn2d.  `act` = (out_scale[planes]|None, noise[HW]|None, noise_w|None, bias[C]|None).
-    planar_hw=(in_h, in_w): x is the phase-planar [N,C,2,2,(in_h+1)/2,(in_w+1)/2] image the UP conv writes."""
+    planar_hw=(in_h, in_w): x is the phase-planar [N,C,2,2,(in_h+1)/2,(in_w+1)/2] image the UP conv writes.
+    `out`: a contiguous [n,c,out_h,out_w] tensor to write (e.g. the tail rows of a larger batch) instead of allocating."""
     n, c = x.shape[0], x.shape[1]
     h, w = planar_hw if planar_hw is not None else (x.shape[2], x.shape[3])
     kh, kw = kernel.shape
-    y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32)
     if act is None:
         a = (0, None, None, None, None, 1, 0.2, SQRT2)
     else:
@@ -154,9 +157,10 @@ def conv_pack(weight, scale, transpose, flip):
 MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 
 
-def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None, out=None):
+def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None, out=None, dot_out=None):
     """One call of w2e_modconv3x3.  h,w: input size for SAME/UP, output size for DOWN.  `out`: write into this
-    (contiguous, [b,n,h,w]) tensor -- e.g. the tail rows of a larger batch -- instead of allocating."""
+    (contiguous, [b,n,h,w]) tensor -- e.g. the tail rows of a larger batch -- instead of allocating; `dot_out`: likewise a
+    ZEROED [b,n] tensor for the fused per-channel dot (accumulated with atomics)."""
     b, k = x.shape[0], x.shape[1]
     n = wp.shape[3]
     if wp.shape[0] != (k + 7) // 8:
@@ -167,7 +171,9 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
         y = out
     else:
         y = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
-    dot = torch.zeros((b, n), device=x.device, dtype=torch.float32) if dot_with is not None else None
+    dot = None
+    if dot_with is not None:
+        dot = dot_out if dot_out is not None else torch.zeros((b, n), device=x.device, dtype=torch.float32)
     noise = noise_w = bias = None
     if act is not None:
         noise, noise_w, bias = act
@@ -180,10 +186,11 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     return y, dot
 
 
-def _channel_dot(a, b):
+def _channel_dot(a, b, out=None):
     """[B,C] = sum_p a*b per plane (w2e_channel_sums: one wave per plane, fixed reduction order)."""
     n, c = a.shape[0], a.shape[1]
-    out = torch.empty((n, c), device=a.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, c), device=a.device, dtype=torch.float32)
     call("w2e_channel_sums", ptr(a), ptr(b), ptr(out), n, c, a.shape[2] * a.shape[3], stream_ptr())
     return out
 
@@ -255,8 +262,11 @@ class _StyledConv(torch.autograd.Function):
             d = d[n_skip:] if d is not None else None
         b, cin, h, w = x.shape
         cout, oh, ow = out.shape[1], out.shape[2], out.shape[3]
+        # inside `nograd_prefix`: full-batch gradient buffers whose tails the kernels write in place; the prefix rows of the
+        # image-sized one stay unwritten (the producer node slices them off the same way), the [B,C]-sized one is zeroed
         gx_full = torch.empty((full, cin, h, w), device=x.device, dtype=torch.float32) if n_skip else None
         gx_out = gx_full[n_skip:] if n_skip else None
+        gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device)
         g_bias = g_nw = sums = dz = None
         if fuse_act:
             gpre = torch.empty_like(out)
@@ -280,18 +290,18 @@ class _StyledConv(torch.autograd.Function):
             # the fused dot epilogue joins the workgroups of a (b, channel) with fp32 atomics; here instead: the unscaled
             # input gradient, its per-channel dot with x by a fixed-order wave reduction, then the out_scale
             raw, _ = _modconv_raw(mode, gpre, wp_b, d, None, h, w)
-            gs = _channel_dot(raw, x)
+            gs = _channel_dot(raw, x, out=gs_out)
             gx = _scale_planes(raw, s)
             if n_skip:
                 gx_out.copy_(gx)
         else:
-            gx, gs = _modconv_raw(mode, gpre, wp_b, d, s, h, w, dot_with=x, out=gx_out)
+            gx, gs = _modconv_raw(mode, gpre, wp_b, d, s, h, w, dot_with=x, out=gx_out, dot_out=gs_out)
         if d is not None:  # + the demodulation path: gs -= s * (dz*d^2) @ wsq, with dz = sum_p gpre*(pre - nw*noise - bias)
             call("w2e_demod_bwd", ptr(sums), ptr(dz), ptr(noise_w) if (fuse_act and noise is not None) else None,
                  ptr(bias) if fuse_act else None, ptr(d), ptr(s), ptr(wsq), ptr(gs), None, b, cin, cout, stream_ptr())
         if n_skip:
-            gx, gs = gx_full, _pad_rows(gs, n_skip)
-        return gx, gs, None, None, g_nw, g_bias, None, None, None, None
+            gx = gx_full
+        return gx, gs_full, None, None, g_nw, g_bias, None, None, None, None
 
 
 def styled_conv(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample):
@@ -345,10 +355,10 @@ class _StyleAffineAll(torch.autograd.Function):
         parts = [(g[n_skip:].reshape(-1) if g is not None else torch.zeros(b * cw, device=w.device, dtype=torch.float32))
                  for g, cw in zip(gs, widths)]
         flat = torch.cat(parts)
-        glat = torch.empty((b, n_latent, dim), device=w.device, dtype=torch.float32)
+        glat_full, glat = _zeros_with_tail(b + n_skip, n_skip, (n_latent, dim), w.device)
         call("w2e_style_affine_bwd", ptr(flat), ptr(w), ctypes.c_void_p(meta.data_ptr()), ptr(glat), b, n_latent, dim,
              w.shape[0], stream_ptr())
-        return _pad_rows(glat, n_skip), None
+        return glat_full, None
 
 
 def style_affine_all(latent, pack):
@@ -357,21 +367,30 @@ def style_affine_all(latent, pack):
 
 # ------------------------------------------------------------------------------------------ K1r
 class _ToRGB(torch.autograd.Function):
-    """`passthrough`: also return x itself as a second output for the NEXT layer to consume.  x then has this node as its
+    """`style` None: wmod is the per-sample [B,3,cin] weight; else wmod is the shared (frozen) [3,cin] scale*W and the kernels
+    form wmod[c,i]*style[b,i] themselves, the backward returning the style gradient directly (w2e_torgb_styled_*).
+    `passthrough`: also return x itself as a second output for the NEXT layer to consume.  x then has this node as its
     only consumer, and the gradient coming back through the next layer arrives here as `gx_next` and is folded into the
     ToRGB input gradient by the kernel (w2e_torgb_bwd_acc) -- instead of autograd adding two activation-sized tensors."""
 
     @staticmethod
-    def forward(ctx, x, wmod, bias, skip, upk, passthrough=False):
+    def forward(ctx, x, wmod, style, bias, skip, upk, passthrough=False):
         x_in = x
         x, wmod = _c(x), _c(wmod)
         b, cin, h, w = x.shape
         y = torch.empty((b, 3, h, w), device=x.device, dtype=torch.float32)
         skip_c = _c(skip) if skip is not None else None
         bias_c = _c(bias.reshape(-1)) if bias is not None else None
-        call("w2e_torgb_fwd", ptr(x), ptr(wmod), ptr(bias_c), ptr(skip_c), ptr(upk) if skip is not None else None,
-             ptr(y), b, cin, h, w, stream_ptr())
-        ctx.save_for_backward(x, wmod, upk if skip is not None else None)
+        if style is None:
+            call("w2e_torgb_fwd", ptr(x), ptr(wmod), ptr(bias_c), ptr(skip_c), ptr(upk) if skip is not None else None,
+                 ptr(y), b, cin, h, w, stream_ptr())
+        else:
+            style = _c(style.reshape(b, cin))
+            if wmod.numel() != 3 * cin:
+                raise RuntimeError(f"to_rgb: the shared weight must be [3,{cin}], got {tuple(wmod.shape)}")
+            call("w2e_torgb_styled_fwd", ptr(x), ptr(wmod), ptr(style), ptr(bias_c), ptr(skip_c),
+                 ptr(upk) if skip is not None else None, ptr(y), b, cin, h, w, stream_ptr())
+        ctx.save_for_backward(x, wmod, style, upk if skip is not None else None)
         ctx.has = (bias is not None, skip is not None, tuple(bias.shape) if bias is not None else None)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
         if passthrough:
@@ -381,32 +400,43 @@ class _ToRGB(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, gx_next=None):
-        x, wmod, upk = ctx.saved_tensors
+        x, wmod, style, upk = ctx.saved_tensors
         has_bias, has_skip, bias_shape = ctx.has
         n_skip = ctx.n_skip
         b, cin, h, w = x.shape
         if gy is None:  # only the pass-through output was used
-            return gx_next, None, None, None, None, None
+            return gx_next, None, None, None, None, None, None
         gy = _c(gy)
         gx = torch.empty_like(x)
         acc = _c(gx_next) if gx_next is not None else None
         if n_skip:  # the tails of batch-major tensors: contiguous views, written / read in place
-            xs, ws, gys, gxs = x[n_skip:], wmod[n_skip:], gy[n_skip:], gx[n_skip:]
+            xs, gys, gxs = x[n_skip:], gy[n_skip:], gx[n_skip:]
             accs = acc[n_skip:] if acc is not None else None
         else:
-            xs, ws, gys, gxs, accs = x, wmod, gy, gx, acc
-        gw = torch.empty_like(ws)
-        call("w2e_torgb_bwd_acc", ptr(xs), ptr(ws), ptr(gys), ptr(accs), ptr(gxs), ptr(gw), b - n_skip, cin, h, w, stream_ptr())
-        gb = gys.sum((0, 2, 3)).reshape(bias_shape) if (has_bias and ctx.needs_input_grad[2]) else None
+            xs, gys, gxs, accs = x, gy, gx, acc
+        if style is None:
+            gw_full, gw = _zeros_with_tail(b, n_skip, (3, cin), x.device)
+            call("w2e_torgb_bwd_acc", ptr(xs), ptr(wmod[n_skip:] if n_skip else wmod), ptr(gys), ptr(accs), ptr(gxs), ptr(gw),
+                 b - n_skip, cin, h, w, stream_ptr())
+            g_wmod, g_style = gw_full.view_as(wmod), None
+        else:
+            gst_full, gst = _zeros_with_tail(b, n_skip, (cin,), x.device)
+            call("w2e_torgb_styled_bwd", ptr(xs), ptr(wmod), ptr(style[n_skip:] if n_skip else style), ptr(gys), ptr(accs),
+                 ptr(gxs), ptr(gst), b - n_skip, cin, h, w, stream_ptr())
+            g_wmod, g_style = None, gst_full
+        gb = gys.sum((0, 2, 3)).reshape(bias_shape) if (has_bias and ctx.needs_input_grad[3]) else None
         gskip = None
         if has_skip:  # adjoint of Upsample(up=2, pad=(2,1)): down=2, un-flipped taps, leading pad 4-1-2
-            gskip = _pad_rows(_upfirdn2d_raw(gys, upk, h // 2, w // 2, 1, 2, 1, 1, False), n_skip)
-        return gx, _pad_rows(gw, n_skip), gb, gskip, None, None
+            gskip = torch.empty((b, 3, h // 2, w // 2), device=x.device, dtype=torch.float32)  # rows [:n_skip]: see _StyledConv
+            _upfirdn2d_raw(gys, upk, h // 2, w // 2, 1, 2, 1, 1, False, out=gskip[n_skip:] if n_skip else gskip)
+        return gx, g_wmod, g_style, gb, gskip, None, None
 
 
-def to_rgb(x, wmod, bias, skip, upk, passthrough=False):
-    """y = sum_i wmod[b,c,i] x[b,i] + bias + Upsample(skip)   (model.py:353-362); with `passthrough` -> (y, x)."""
-    return _ToRGB.apply(x, wmod, bias, skip, upk, passthrough)
+def to_rgb(x, wmod, bias, skip, upk, passthrough=False, style=None):
+    """y = sum_i wmod[b,c,i] x[b,i] + bias + Upsample(skip)   (model.py:353-362); with `passthrough` -> (y, x).
+    With `style` [B,cin]: wmod is the shared [3,cin] scale*W (treated as frozen) and the weight of sample b is
+    wmod[c,i]*style[b,i]."""
+    return _ToRGB.apply(x, wmod, style, bias, skip, upk, passthrough)
 
 
 # ------------------------------------------------------------------------------------------ K5

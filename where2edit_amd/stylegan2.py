@@ -344,22 +344,24 @@ class ToRGB(nn.Module):
         style = conv._style(style, batch, input_is_stylespace)
         # wmod[b,c,i] = scale * W[c,i] * s[b,i]  (model.py:239 with k=1, demodulate=False)
         w = conv.weight
+        st = None
         if torch.is_grad_enabled() and w.requires_grad:
-            wsc = conv.scale * w.view(1, 3, conv.in_channel)
-        else:  # frozen decoder: scale*W is cached until the parameter changes
+            wmod = (conv.scale * w.view(1, 3, conv.in_channel)) * style.reshape(batch, 1, conv.in_channel)
+        else:  # frozen decoder: scale*W is cached until the parameter changes, and the kernels apply the style themselves
             key = (w.data_ptr(), w._version)
             if getattr(self, "_wsc_key", None) != key:
                 with torch.no_grad():
-                    self._wsc = (conv.scale * w.detach().view(1, 3, conv.in_channel)).contiguous()
+                    self._wsc = (conv.scale * w.detach().view(3, conv.in_channel)).contiguous()
                 self._wsc_key = key
-            wsc = self._wsc
-        wmod = wsc * style.reshape(batch, 1, conv.in_channel)
+            wmod, st = self._wsc, style.reshape(batch, conv.in_channel)
         fuse_skip = skip is not None and self.upsample.kernel.shape == (4, 4) and self.upsample.factor == 2
         passed = None
         if passthrough:
-            out, passed = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None, True)
+            out, passed = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None,
+                                   True, style=st)
         else:
-            out = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None)
+            out = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None,
+                           style=st)
         if skip is not None and not fuse_skip:
             out = out + self.upsample(skip)
         if passthrough:
