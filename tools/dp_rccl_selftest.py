@@ -1,13 +1,34 @@
-import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, os.getcwd())
+#!/usr/bin/env python3
+"""RCCL self-test on ONE GPU: a world-size-1 nccl process group (its watchdog thread included), the data-parallel Coach with the
+flat gradient bucket, eager steps, then the hipGraph-captured step with the all-reduce after each replay -- what
+`bench.py --gpus N` runs per rank.  usage: dp_rccl_selftest.py [size batch]"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+SIZE = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
-import bench
-coach = bench.build_coach(256, 2, "cuda:0", True, "hip")
-w = bench.synthetic_latents(coach.net.decoder, 2, 0)
+import bench  # noqa: E402
+
+coach = bench.build_coach(SIZE, B, "cuda:0", True, "hip")
+w = bench.synthetic_latents(coach.net.decoder, B, 0)
 for _ in range(3):
     d = coach.train_step(w)
-dist.barrier(); torch.cuda.synchronize()
-print("RCCL world-1 DP step ok, loss", float(d["loss"]), "bucket MB", coach.bucket.nbytes / 1e6)
+dist.barrier()
+torch.cuda.synchronize()
+print("RCCL world-1 DP eager step ok, loss", float(d["loss"]), "bucket MB", coach.bucket.nbytes / 1e6, flush=True)
+step = coach.capture_step(w)
+for _ in range(5):
+    d = step(w)
+dist.barrier()
+torch.cuda.synchronize()
+loss = float(d["loss"])
+assert loss == loss, "NaN loss after graph replays"
+print("RCCL world-1 DP graphed step ok, loss", loss, flush=True)
 dist.destroy_process_group()
