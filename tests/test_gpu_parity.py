@@ -594,6 +594,56 @@ def test_to_rgb_passthrough_joins_gradients(cin, h, with_skip):
         assert_close(a, bb, 1e-6, name)
 
 
+def _to_planar(t, fill):
+    """[N,C,2h+1,2w+1] -> the UP conv's phase-planar [N,C,2,2,h+1,WP] (WP = w+1 padded to a multiple of 4), padding = fill."""
+    n, c, ih, iw = t.shape
+    hp, wp = (ih + 1) // 2, ((iw + 1) // 2 + 3) // 4 * 4
+    out = torch.full((n, c, 2, 2, hp, wp), fill, device=t.device, dtype=t.dtype)
+    for py in range(2):
+        for px in range(2):
+            sub = t[:, :, py::2, px::2]
+            out[:, :, py, px, :sub.shape[2], :sub.shape[3]] = sub
+    return out
+
+
+@pytest.mark.parametrize("h,w,separable", [(128, 128, True), (130, 256, True), (96, 128, False), (33, 512, True)])
+@pytest.mark.parametrize("act", [False, True])
+def test_upfirdn_stream_planar_equals_reference_form(h, w, separable, act, w2e_opt):
+    """The streaming 4x4 kernel (wide images) on the UP conv's phase-planar T': same result as the dense generic kernel on the
+    plain image, strips that end mid-way, a non-separable kernel, NaN in the layout's padding (never read)."""
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(3 * h + w)
+    c = 3
+    t = torch.randn(2, c, 2 * h + 1, 2 * w + 1, generator=g).to(DEV)
+    k4 = cu(seeded.fir_kernel(gain=4.0))
+    if not separable:
+        k4 = k4 + 0.05 * torch.randn(4, 4, generator=g).to(DEV)
+    a = (None, torch.randn(1, 1, 2 * h, 2 * w, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV), torch.randn(c, generator=g).to(DEV)) if act else None
+    y = K._upfirdn2d_raw(_to_planar(t, float("nan")), k4, 2 * h, 2 * w, 1, 1, 1, 1, True, act=a, planar_hw=(2 * h + 1, 2 * w + 1))
+    w2e_opt("tune_blur", "8")  # the tile kernels
+    ref = K._upfirdn2d_raw(t, k4, 2 * h, 2 * w, 1, 1, 1, 1, True, act=a)
+    assert torch.isfinite(y).all()
+    assert_close(y, ref, 2e-6, "stream planar")
+
+
+@pytest.mark.parametrize("h,w,separable", [(128, 128, True), (100, 256, True), (64, 130, False), (40, 514, True), (30, 131, True)])
+def test_upfirdn_stream_dense_adjoint_equals_tile_kernel(h, w, separable, w2e_opt):
+    """The streaming kernel on a dense source (the adjoint blur: pad 2, un-flipped taps, output one wider and taller than the
+    input): odd output widths (the single last column), ragged widths, strips that end after one row."""
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(5 * h + w)
+    gy = torch.randn(2, 3, 2 * h, 2 * w, generator=g).to(DEV)
+    k4 = cu(seeded.fir_kernel(gain=1.0))
+    if not separable:
+        k4 = k4 + 0.05 * torch.randn(4, 4, generator=g).to(DEV)
+    for oh, ow in ((2 * h + 1, 2 * w + 1), (2 * h, 2 * w - 1), (2 * h - 3, 2 * w - 2)):
+        w2e_opt("tune_blur", "0")
+        y = K._upfirdn2d_raw(gy, k4, oh, ow, 1, 1, 2, 2, False)
+        w2e_opt("tune_blur", "8")
+        ref = K._upfirdn2d_raw(gy, k4, oh, ow, 1, 1, 2, 2, False)
+        assert_close(y, ref, 2e-6, f"stream dense {oh}x{ow}")
+
+
 @pytest.mark.parametrize("cin,h,with_skip,prefix", [(32, 64, True, 0), (12, 18, False, 0), (512, 8, True, 1), (64, 128, True, 2)])
 def test_to_rgb_styled_equals_per_sample_weight(cin, h, with_skip, prefix):
     """w2e_torgb_styled_*: the kernels form scale*W[c,i]*style[b,i] themselves and return the style gradient; same image and

@@ -31,31 +31,46 @@ def _stale():
 
 
 def build(force=False, verbose=True):
-    """Compile every .hip under csrc/ into lib/libw2e.so.  Raises on any compiler error."""
+    """Compile every .hip under csrc/ into lib/libw2e.so.  Raises on any compiler error.  Objects are kept under lib/obj/
+    (git-ignored) and a translation unit is recompiled only when it, a header or the flags changed."""
     if not force and not _stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
+    stamp = os.path.join(obj_dir, "flags.txt")
+    flags_now = " ".join(FLAGS)
+    if force or not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        for o in glob.glob(os.path.join(obj_dir, "*.o")):
+            os.remove(o)
     objs = []
     procs = []
-    for src in sources():  # one hipcc per translation unit, in parallel
-        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+    for src in sources():  # one hipcc per stale translation unit, in parallel
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
+        if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + headers):
+            continue
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, pr in procs:
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = None
+    for src, obj, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
+            if os.path.exists(obj):
+                os.remove(obj)
+            failed = failed or f"hipcc failed on {src}:\n{out}"
+        elif verbose and out.strip():
             print(out)
+    if failed:
+        raise RuntimeError(failed)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    for o in objs:
-        os.remove(o)
     if verbose:
-        print(f"built {LIB_PATH}")
+        print(f"built {LIB_PATH} ({len(procs)} of {len(objs)} translation units recompiled)")
     return LIB_PATH
 
 

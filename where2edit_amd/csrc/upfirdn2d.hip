@@ -320,6 +320,257 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
     }
 }
 
+// 4x4 FIR, up = down = 1, wide images (out_w >= 256): a streaming form without LDS or barriers.
+//  * A wave owns a 256-column x SR-row strip of one plane; a lane owns 4 adjacent output columns and walks DOWN the strip.
+//    Each source row is read once per lane as a 7-wide window, three rows ahead of its use, and the vertical reuse lives in
+//    registers: a source row is scattered into the 4 output rows it feeds (separable kernels: one 4-tap horizontal pass, then
+//    4 scaled adds); the oldest of the 4 open output rows is then finished, run through the fused epilogue and stored as one
+//    float4 per lane (1 KB per wave; row offsets on the scalar unit).  The noise row of the epilogue is fetched with the
+//    window that closes its output row, so no wait ever drains the loads in flight.
+//  * The window is held as the PAIRS the packed-fp32 FMAs (v_pk_fma_f32) consume, each pair loaded as one 8-byte buffer load:
+//    PLANAR (the UP conv's phase-planar T', pad_x0 = 1): outputs are paired (0,2),(1,3); the pairs (w0,w2),(w2,w4),(w4,w6) are
+//    consecutive entries of the odd-column plane and (w1,w3),(w3,w5) of the even-column plane.  Dense source (in_w a multiple
+//    of 4, pad_x0 = 2: the adjoint blur): outputs are paired (0,1),(2,3) and the pairs are (w_i, w_i+1), i = 0..5.
+//    A pair that straddles the image's left / right edge is fixed up by a select in the waves that hold such a lane; whole
+//    pairs outside the image, and rows outside it, fall past a descriptor and read as 0.
+//  * Dense source with an odd out_w (in_w + 1): the lane owning the last full group also computes the single last column.
+constexpr int SR = 64;  // strip rows per wave (3 halo rows re-read per strip: 4.7 %)
+
+template <bool ACT, bool PLANAR>
+__global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, int col_groups, int strips) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NP = PLANAR ? 5 : 1;  // 8-byte pairs loaded per window
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int per_plane = col_groups * strips;
+    const int plane = wid / per_plane;
+    if (plane >= (int)p.planes) return;
+    const int rem = wid - plane * per_plane;
+    const int strip = rem / col_groups, cg = rem - strip * col_groups;
+    const int y0 = strip * SR;
+    const int m = cg * 64 + lane;  // this lane's 4-column group
+    const int ox = 4 * m;
+
+    float kr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kr[i] = p.flip ? p.kern[15 - i] : p.kern[i];
+    float kh[4], kv[4];
+    bool separable = kr[0] != 0.f;
+    {
+        float kmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kmax = fmaxf(kmax, fabsf(kr[i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kh[i] = kr[i], kv[i] = separable ? kr[4 * i] / kr[0] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) separable = separable && fabsf(kr[i] - kv[i >> 2] * kh[i & 3]) <= 1e-7f * kmax;
+    }
+
+    // ---- source addressing.  Window columns: w_i = source column ox - pad_x0 + i, i = 0..6 (7 = 0).
+    const int hp = (p.in_h + 1) >> 1, wpp = (((p.in_w + 1) >> 1) + 3) & ~3;
+    const int64_t plane_stride = PLANAR ? (int64_t)4 * hp * wpp : (int64_t)p.in_h * p.in_w;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)plane * plane_stride), (short)0,
+                                                                        (int)(plane_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), (short)0, 0, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int c0 = ox - p.pad_x0;  // source column of w_0
+    auto col_ok = [&](int c) { return c >= 0 && c < p.in_w; };
+    // pair q: (first window index, second window index); byte offset of the pair inside its source row; which row plane
+    unsigned voff[NP];
+    unsigned fix_lo = 0, fix_hi = 0;  // bit q: the pair's first / second element lies outside the image while the other is inside
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        int ia, ib, idx;
+        if (PLANAR) {  // q = 0,1,2: odd-column plane (w0,w2),(w2,w4),(w4,w6); q = 3,4: even-column plane (w1,w3),(w3,w5)
+            ia = q < 3 ? 2 * q : 2 * (q - 3) + 1, ib = ia + 2;
+            idx = (c0 + ia) >> 1;  // entry of its parity plane (floor: c0 + ia may be -1)
+        } else {
+            ia = q, ib = q + 1;
+            idx = c0 + ia;
+        }
+        const bool oka = col_ok(c0 + ia), okb = col_ok(c0 + ib);
+        voff[q] = (oka || okb) ? (unsigned)idx * 4u : OOB;
+        if (!oka && okb) fix_lo |= 1u << q, voff[q] = (unsigned)(idx + 1) * 4u;  // fetch one entry later, shift up by the select
+        if (oka && !okb) fix_hi |= 1u << q;
+    }
+    const bool wave_fix = PLANAR && __builtin_amdgcn_ballot_w64((fix_lo | fix_hi) != 0) != 0ull;  // (uniform)
+    unsigned vd[3];  // dense: w0,w1 (8 B) | w2..w5 (16 B) | w6 (4 B)
+    vd[0] = (col_ok(c0) && col_ok(c0 + 1)) ? (unsigned)c0 * 4u : OOB;
+    vd[1] = (col_ok(c0 + 2) && col_ok(c0 + 5)) ? (unsigned)(c0 + 2) * 4u : OOB;
+    vd[2] = col_ok(c0 + 6) ? (unsigned)(c0 + 6) * 4u : OOB;
+    struct Win {
+        f32x2 q[NP];  // PLANAR: the pairs as loaded.  Dense: q[0] = (w0,w1), then the 16-byte group d4 = w2..w5 and d1 = w6;
+        f32x4 d4;     //         the three pairs that straddle those loads are put together where they are consumed
+        float d1;
+    };
+    // (`need` false: a row nobody will consume -- the load is still ISSUED, against the empty descriptor, so that every path
+    // through the loop has the same number of loads in flight and the compiler's counter waits stay partial)
+    auto load_row = [&](int r, Win& w, bool need) __attribute__((always_inline)) {
+        const bool ok = need && r >= 0 && r < p.in_h && !(p.tune & 1);
+        const __amdgpu_buffer_rsrc_t rs = ok ? rx : rzero;
+        unsigned so = 0u, se = 0u;
+        if (ok) {
+            if (PLANAR) {  // column parity of w_0 = parity of pad_x0 (odd): the pairs q0..q2 live in plane px = that parity
+                const int par0 = p.pad_x0 & 1;  // (ox is a multiple of 4; kept off the lane id so that the offsets stay scalar)
+                so = (unsigned)((((r & 1) * 2 + par0) * hp + (r >> 1)) * wpp) * 4u;
+                se = (unsigned)((((r & 1) * 2 + (par0 ^ 1)) * hp + (r >> 1)) * wpp) * 4u;
+            } else {
+                so = se = (unsigned)(r * p.in_w) * 4u;
+            }
+        }
+        if (PLANAR) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                w.q[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q], q >= 3 ? se : so, 0));
+        } else {  // in_w % 4 == 0: each of the three loads is wholly inside or wholly outside the row
+            w.q[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vd[0], so, 0));
+            w.d4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vd[1], so, 0));
+            w.d1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vd[2], so, 0));
+        }
+    };
+    auto fix_row = [&](Win& w) __attribute__((always_inline)) {  // only in waves that hold an edge lane
+        if (!wave_fix) return;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (fix_lo & (1u << q)) w.q[q][1] = w.q[q][0], w.q[q][0] = 0.f;  // (the load was shifted one entry up)
+            if (fix_hi & (1u << q)) w.q[q][1] = 0.f;
+        }
+    };
+
+    // ---- destination and epilogue constants
+    const unsigned out_bytes = (unsigned)(p.out_h * p.out_w) * 4u;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)plane * p.out_h * p.out_w, (short)0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACT && p.noise ? p.noise : p.x), (short)0,
+                                                                      (ACT && p.noise) ? (int)out_bytes : 0, 0x00020000);
+    const bool full4 = ox + 3 < p.out_w;
+    const bool edge5 = !PLANAR && (p.out_w & 3) == 1 && ox + 4 == p.out_w - 1;  // this lane also owns the single last column
+    const bool wave_edge5 = !PLANAR && __builtin_amdgcn_ballot_w64(edge5) != 0ull;  // (uniform)
+    const unsigned vout = ox < p.out_w ? (unsigned)ox * 4u : OOB;
+    // (v*scale + bias + nw*noise) -> lrelu -> *gain  ==  lrelu(v*scale*gain + bias*gain + nw*gain*noise) for gain > 0
+    const bool fold = ACT && p.gain > 0.f && p.slope >= 0.f && p.slope <= 1.f;  // (uniform) then lrelu(e) = max(e, slope*e)
+    const float g1 = fold ? p.gain : 1.f;
+    const float nw = (ACT && p.noise) ? p.noise_w[0] * g1 : 0.f;
+    float e_scale = g1, e_bias = 0.f;
+    if (ACT) {
+        if (p.out_scale) e_scale *= p.out_scale[plane];
+        if (p.bias) e_bias = p.bias[plane % p.channels] * g1;
+    }
+
+    // open output rows: slot j holds the row with (Y - y0) & 3 == j as the output pairs A, B (+ the single last column)
+    f32x2 accA[4], accB[4];
+    float acc5[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accA[j] = accB[j] = f32x2{0.f, 0.f}, acc5[j] = 0.f;
+
+    // source row r0 + k feeds output row y0 + k - a with kernel row a (a <= a_hi: rows of THIS strip); y0 % 4 == 0, so the
+    // accumulator slot (k - a) & 3 is a compile-time constant at every call site (k_phase = k & 3 is passed as a literal)
+    auto scatter = [&](const Win& w, const int k_phase, const int a_hi) __attribute__((always_inline)) {
+        if (p.tune & 2) return;
+        // taps of output pair A / B: PLANAR A = outputs (0,2): (w0,w2),(w1,w3),(w2,w4),(w3,w5) = q0,q3,q1,q4;  B = (1,3): q3,q1,q4,q2
+        //                            dense  A = outputs (0,1): q0,q1,q2,q3;                                     B = (2,3): q2,q3,q4,q5
+        f32x2 dq[6];
+        if (!PLANAR) {
+            dq[0] = w.q[0], dq[1] = f32x2{w.q[0][1], w.d4[0]}, dq[2] = f32x2{w.d4[0], w.d4[1]}, dq[3] = f32x2{w.d4[1], w.d4[2]};
+            dq[4] = f32x2{w.d4[2], w.d4[3]}, dq[5] = f32x2{w.d4[3], w.d1};
+        }
+        const f32x2 tA0 = PLANAR ? w.q[0] : dq[0], tA1 = PLANAR ? w.q[3] : dq[1], tA2 = PLANAR ? w.q[1] : dq[2], tA3 = PLANAR ? w.q[4] : dq[3];
+        const f32x2 tB0 = PLANAR ? w.q[3] : dq[2], tB1 = PLANAR ? w.q[1] : dq[3], tB2 = PLANAR ? w.q[4] : dq[4], tB3 = PLANAR ? w.q[2] : dq[5];
+        // single last column (dense): w4, w5, w6
+        const float t50 = PLANAR ? 0.f : w.d4[2], t51 = PLANAR ? 0.f : w.d4[3], t52 = PLANAR ? 0.f : w.d1;
+        if (separable) {
+            const f32x2 hA = kh[0] * tA0 + kh[1] * tA1 + kh[2] * tA2 + kh[3] * tA3;
+            const f32x2 hB = kh[0] * tB0 + kh[1] * tB1 + kh[2] * tB2 + kh[3] * tB3;
+            const float h5 = wave_edge5 ? kh[0] * t50 + kh[1] * t51 + kh[2] * t52 : 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a > a_hi) continue;
+                const int slot = (k_phase - a) & 3;
+                accA[slot] += kv[a] * hA, accB[slot] += kv[a] * hB;
+                if (wave_edge5) acc5[slot] += kv[a] * h5;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a > a_hi) continue;
+                const int slot = (k_phase - a) & 3;
+                accA[slot] += kr[a * 4] * tA0 + kr[a * 4 + 1] * tA1 + kr[a * 4 + 2] * tA2 + kr[a * 4 + 3] * tA3;
+                accB[slot] += kr[a * 4] * tB0 + kr[a * 4 + 1] * tB1 + kr[a * 4 + 2] * tB2 + kr[a * 4 + 3] * tB3;
+                if (wave_edge5) acc5[slot] += kr[a * 4] * t50 + kr[a * 4 + 1] * t51 + kr[a * 4 + 2] * t52;
+            }
+        }
+    };
+    auto load_noise = [&](int Y, bool need) __attribute__((always_inline)) {
+        if (!ACT) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = need && Y < p.out_h;  // (uniform)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rn : rzero, vout, ok ? (unsigned)(Y * p.out_w) * 4u : 0u, 0));
+    };
+    auto emit = [&](int Y, const int slot, const f32x4 nz) __attribute__((always_inline)) {
+        float v[4];
+        if (PLANAR) v[0] = accA[slot][0], v[2] = accA[slot][1], v[1] = accB[slot][0], v[3] = accB[slot][1];
+        else v[0] = accA[slot][0], v[1] = accA[slot][1], v[2] = accB[slot][0], v[3] = accB[slot][1];
+        const float v5 = acc5[slot];
+        accA[slot] = accB[slot] = f32x2{0.f, 0.f}, acc5[slot] = 0.f;
+        if (Y >= p.out_h) return;  // (uniform)
+        const unsigned srow = (unsigned)(Y * p.out_w) * 4u;
+        if (ACT) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float e = v[c] * e_scale + e_bias + nw * nz[c];
+                v[c] = fold ? fmaxf(e, e * p.slope) : (e > 0.f ? e : e * p.slope) * p.gain;
+            }
+        }
+        if ((p.tune & 4) && v[0] != 123456.75f) return;
+        f32x4 o;
+        o[0] = v[0], o[1] = v[1], o[2] = v[2], o[3] = v[3];
+        if (PLANAR || (p.out_w & 3) == 0) {  // every lane: a whole group or nothing (past the descriptor: dropped)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), ry, vout, srow, 0);
+        } else {
+            if (full4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), ry, vout, srow, 0);
+            } else if (vout != OOB) {  // ragged right edge
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (ox + c < p.out_w) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[c]), ry, vout + 4u * c, srow, 0);
+            }
+            if (wave_edge5 && edge5) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v5), ry, vout + 16u, srow, 0);
+        }
+    };
+
+    // rows: the strip's outputs y0 .. y0+SR-1 need source rows r0 .. r0 + SR + 2, r0 = y0 - pad_y0; source row r0 + 3 + i closes
+    // output row y0 + i, whose noise row travels with it (issued BEFORE that window's loads: the counter waits stay partial)
+    const int r0 = y0 - p.pad_y0;
+    Win w0, w1, w2, w3;
+    f32x4 n0, n1, n2, n3;
+    load_row(r0, w0, true), load_row(r0 + 1, w1, true), load_row(r0 + 2, w2, true);
+    n0 = load_noise(y0, true), load_row(r0 + 3, w3, true);
+    // prologue: the first three source rows only open output rows >= y0  (kernel rows a <= k)
+    fix_row(w0), scatter(w0, 0, 0);
+    n1 = load_noise(y0 + 1, true), load_row(r0 + 4, w0, true);
+    fix_row(w1), scatter(w1, 1, 1);
+    n2 = load_noise(y0 + 2, true), load_row(r0 + 5, w1, true);
+    fix_row(w2), scatter(w2, 2, 2);
+    n3 = load_noise(y0 + 3, true), load_row(r0 + 6, w2, true);
+    int rows = p.out_h - y0;  // output rows of this strip
+    rows = rows < SR ? rows : SR;
+    for (int i = 0; i < rows; i += 4) {
+        const bool more = i + 4 < rows;  // (the last group needs source rows up to r0 + i + 6 only: already in flight)
+        fix_row(w3), scatter(w3, 3, 3);
+        emit(y0 + i, 0, n0);
+        n0 = load_noise(y0 + i + 4, more), load_row(r0 + 7 + i, w3, more);
+        fix_row(w0), scatter(w0, 0, 3);
+        emit(y0 + i + 1, 1, n1);
+        n1 = load_noise(y0 + i + 5, more), load_row(r0 + 8 + i, w0, more);
+        fix_row(w1), scatter(w1, 1, 3);
+        emit(y0 + i + 2, 2, n2);
+        n2 = load_noise(y0 + i + 6, more), load_row(r0 + 9 + i, w1, more);
+        fix_row(w2), scatter(w2, 2, 3);
+        emit(y0 + i + 3, 3, n3);
+        n3 = load_noise(y0 + i + 7, more), load_row(r0 + 10 + i, w2, more);
+    }
+}
+
 // General tap counts (<= MAX_TILE_K per axis), up = down = 1.
 __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int tiles_x, int tiles_y, unsigned pw_magic) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -442,7 +693,24 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
         const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)pw + 1);
         if (kh == 4 && kw == 4) {
             const bool vec = !in_layout && (in_w & 3) == 0 && ((uintptr_t)x & 15) == 0;
-            if (in_layout || vec) {
+            // wide images: the streaming kernel (no LDS, no barriers); tune bit 8 keeps the tile kernels for comparison
+            const bool stream_ok = !(tune & 8) && out_w >= 256 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                                   (in_layout ? (pad_x0 == 1 && (out_w & 3) == 0 && in_w == out_w + 1)
+                                              : (pad_x0 == 2 && (in_w & 3) == 0 && out_w <= in_w + 1));
+            if (stream_ok) {
+                const int lanes = (!in_layout && (out_w & 3) == 1) ? out_w / 4 : (int)ceil_div(out_w, 4);  // (a single last column rides on the last full group)
+                const int col_groups = (int)ceil_div(lanes, 64), strips = (int)ceil_div(out_h, SR);
+                const int64_t waves = planes * col_groups * strips;
+                W2E_REQUIRE(waves < ((int64_t)1 << 31), "upfirdn2d: tensor too large");
+                const unsigned blocks = (unsigned)ceil_div(waves, 4);
+                if (in_layout) {
+                    if (act) upfirdn_stream4_kernel<true, true><<<blocks, 256, 0, s>>>(p, col_groups, strips);
+                    else upfirdn_stream4_kernel<false, true><<<blocks, 256, 0, s>>>(p, col_groups, strips);
+                } else {
+                    if (act) upfirdn_stream4_kernel<true, false><<<blocks, 256, 0, s>>>(p, col_groups, strips);
+                    else upfirdn_stream4_kernel<false, false><<<blocks, 256, 0, s>>>(p, col_groups, strips);
+                }
+            } else if (in_layout || vec) {
                 // aligned-source kernel: each workgroup walks (plane, tile row) items of one tile column; ~8 per CU
                 const int64_t items = planes * tiles_y;
                 int gsteps = 256 * 8 / tiles_x;

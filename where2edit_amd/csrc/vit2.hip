@@ -28,7 +28,10 @@ __device__ __forceinline__ float quick_gelu_grad2(float x) {
 }
 
 // ------------------------------------------------------------------------------------------ gemm_fm
-constexpr int FM_WAVES = 7, FM_ROWS = 32 * FM_WAVES, FM_BN = 32, FM_BK = 32, FM_STAGES = 4;
+#ifndef W2E_FM_STAGES
+#define W2E_FM_STAGES 4
+#endif
+constexpr int FM_WAVES = 7, FM_ROWS = 32 * FM_WAVES, FM_BN = 32, FM_BK = 32, FM_STAGES = W2E_FM_STAGES;
 constexpr int FM_SLOTS = 5;                                   // DMA wave-instructions per wave per K-step (7 x 5 = 35 >= 32)
 constexpr int FM_STAGE_BYTES = (FM_ROWS + FM_BN) * FM_BK * 4;  // 256 rows x 128 B = 32 KB
 constexpr int FM_DUMMY_BYTES = 1024;                           // landing area of the 3 surplus slots
