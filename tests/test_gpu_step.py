@@ -498,6 +498,52 @@ def test_graphed_step_equals_eager_step():
         where2edit_amd.set_deterministic(False)
 
 
+def test_graphed_region_step_with_callable_mask_equals_eager_step():
+    """BASELINE configs[2] under capture: the mask is a function of the unedited pass's activations (a callable, evaluated between
+    the two generator passes) and the id term runs IR-SE50 -- captured with the step.  Same losses and parameters as the eager
+    step over several steps with changing latents, bit for bit in deterministic mode."""
+    import where2edit_amd
+    size = 256
+    where2edit_amd.set_deterministic(True)
+    try:
+        msd = seeded.mapper_state_dict(["course_mapping.", "medium_mapping.", "fine_mapping."])
+
+        def build():
+            opts, net, loss_mod, clip, tokens, _, _, _, Coach, CLIPLoss = _region_id_setup(size)
+            net.mapper.load_state_dict(msd, strict=True)
+            return Coach(opts, net=net, clip_loss=CLIPLoss(opts, model=clip), id_loss=loss_mod, text_inputs=tokens, device=DEV)
+
+        def mask_fn(feats):  # layer 7 of the 256 generator is 16x16: a soft mask from that layer's own features
+            # (elementwise only: torch's multi-block reductions zero their scratch with hipMemsetAsync, and a captured memset
+            # node is not replayed on this ROCm stack -- tools/graph_safety.py lists such operations of a step)
+            f = feats[6]
+            return torch.sigmoid((f[:, 0:1] + f[:, 1:2] - f[:, 2:3]) * 3.0)
+
+        eager, graphed = build(), build()
+        ws = [seeded.wplus_latents(2, OG.n_latent(size), salt=80 + i).to(DEV) for i in range(4)]
+        step = graphed.capture_step(ws[0], mask_fn)
+        for i, w in enumerate(ws):
+            de, dg = eager.train_step(w, mask_fn), step(w)
+            for key in ("loss", "loss_id", "loss_clip"):
+                assert torch.equal(de[key], dg[key]), f"{key} at step {i}"
+            for (n, pe), (_, pg) in zip(eager.net.mapper.named_parameters(), graphed.net.mapper.named_parameters()):
+                assert torch.equal(pe, pg), f"{n} after step {i}"
+    finally:
+        where2edit_amd.set_deterministic(False)
+
+
+def test_capture_refuses_a_step_with_memset_operations():
+    """A callable mask built on a multi-block torch reduction (its scratch is zeroed by hipMemsetAsync) must not be captured:
+    capture_step names the operation and raises."""
+    size = 256
+    opts, net, loss_mod, clip, tokens, _, _, _, Coach, CLIPLoss = _region_id_setup(size)
+    coach = Coach(opts, net=net, clip_loss=CLIPLoss(opts, model=clip), id_loss=loss_mod, text_inputs=tokens, device=DEV)
+    w = seeded.wplus_latents(2, OG.n_latent(size), salt=90).to(DEV)
+    with pytest.raises(RuntimeError, match="memset"):
+        coach.capture_step(w, lambda feats: torch.sigmoid(feats[6].mean(1, keepdim=True) * 3.0))
+    coach.train_step(w, lambda feats: torch.sigmoid(feats[6].mean(1, keepdim=True) * 3.0))  # eager: fine
+
+
 def test_merged_forward_equals_two_passes():
     """Coach.forward_pair runs x = G(w) and x_hat = G(w_hat) as one generator pass over [w; w_hat], with the backward of every
     generator node restricted to the w_hat rows (functional.nograd_prefix).  Same images, losses and mapper gradients as the

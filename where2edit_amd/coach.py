@@ -188,11 +188,11 @@ class Coach:
         eager_side = self._side
         if side_stream and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        if callable(mask):
-            raise RuntimeError("capture_step: pass the mask tensor (a callable mask is evaluated eagerly)")
         s_space = getattr(self.opts, "work_in_stylespace", False)
         static_w = [c.clone() for c in w] if s_space else w.clone()
-        static_mask = mask.clone() if mask is not None else None
+        # a callable mask (features -> mask, e.g. the region-attention net's mask branch) is captured WITH the step: it must be
+        # stream-ordered like everything else (no host synchronisation, no .item(); the warm-up iterations below fill its caches)
+        static_mask = mask if (mask is None or callable(mask)) else mask.clone()
         params = list(self.net.mapper.parameters())
 
         def body():
@@ -213,6 +213,16 @@ class Coach:
                 body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # A captured hipMemsetAsync was observed NOT to be replayed with the graph on this ROCm stack (libw2e.so zero-fills with
+        # kernels for that reason).  torch's multi-block reductions zero their scratch with one, so a step that contains a memset
+        # (e.g. a callable mask with a large .mean()) would replay on stale scratch: refuse it here rather than diverge silently.
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
+            body()
+            torch.cuda.synchronize()
+        memsets = sorted({e.name for e in prof.events() if any("emset" in k.name or "fillBuffer" in k.name for k in (e.kernels or []))})
+        if memsets:
+            raise RuntimeError(f"capture_step: the step issues memset operations (from {', '.join(memsets)}); they are not replayed "
+                               "reliably inside a hipGraph here -- use an elementwise / kernel-based form (tools/graph_safety.py lists them)")
         graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(graph):
@@ -227,7 +237,7 @@ class Coach:
                     dst.copy_(src)
             else:
                 static_w.copy_(w_new)
-            if static_mask is not None and mask_new is not None:
+            if static_mask is not None and mask_new is not None and not callable(static_mask):
                 static_mask.copy_(mask_new)
             graph.replay()
             if self.bucket is not None:
