@@ -92,8 +92,8 @@ def make_mask(coach, batch, size, rank, device, synthetic=False):
         torch.manual_seed(1)
         att_net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
                                                          clusters=20, cluster_dim=576).to(device).requires_grad_(False)
-        with torch.no_grad():
-            att_net.initial_bias.fill_(1.0)  # (the reference's init of 5 saturates the sigmoid: every cluster passes the threshold)
+        with torch.no_grad():  # (the reference's init of 5 saturates the sigmoid: every cluster passes the threshold; logit(0.8)
+            att_net.initial_bias.fill_(1.3863)  # puts the random-init net's cluster means on both sides of it: a mixed mask)
         att_text = torch.randn(batch, 512, generator=torch.Generator().manual_seed(5 + rank)).to(device) * 0.3
         const_in = coach.net.decoder.input.input
 
@@ -107,7 +107,8 @@ def make_mask(coach, batch, size, rank, device, synthetic=False):
                 att_net.store_clusters(torch.cat([pts, xs.to(f.device)[:, None].repeat(1, 32), ys.to(f.device)[:, None].repeat(1, 32)], 1))
             att_net._seeded = True
             each, assign = att_net.attention_map(fm, 64, att_text, 26)
-            return cluster_pool(each, assign, 64, 20)[4]
+            mask.last = cluster_pool(each, assign, 64, 20)[4]
+            return mask.last
         return mask
     res = 4 * 2 ** ((13 - 1) // 3) if size == 1024 else max(4, size // 16)  # seeded U(0,1) at the resolution of layer 13
     return torch.rand(batch, 1, res, res, generator=torch.Generator().manual_seed(77 + rank)).to(device)
@@ -248,11 +249,19 @@ def bench_config5(args, rank, world, device):
     clip = CLIPLoss(opts, model=CLIP(visual_backend=args.clip_backend)).to(device)
     net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
                                                  clusters=20, cluster_dim=576).to(device).eval().requires_grad_(False)
-    with torch.no_grad():
-        net.initial_bias.fill_(1.0)
     gen = torch.Generator().manual_seed(100 + rank)
     imgs = (torch.rand(args.batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
     text, att = (torch.randn(args.batch, 512, generator=gen) * 0.3).to(device), (torch.randn(args.batch, 512, generator=gen) * 0.3).to(device)
+    with torch.no_grad():  # random-init net: logit(0.8) as the bias and 20 pixels of the first batch's layer-13 features as the
+        net.initial_bias.fill_(1.3863)  # cluster centres give a mixed (not all-0 / all-1) thresholded mask, as in make_mask()
+        _, _, styles0 = g([e4e(imgs)], input_is_latent=True, return_latents=True, randomize_noise=False)
+        _, _, _, feats0 = g([styles0], input_is_latent=True, randomize_noise=False, return_features=True, input_is_stylespace=True)
+        f = feats0[12]
+        idx = torch.randperm(64 * 64, generator=torch.Generator().manual_seed(3))[:20]
+        pts = f[0].reshape(512, -1)[:, idx.to(f.device)].t()
+        ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
+        net.store_clusters(torch.cat([pts, xs.to(f.device)[:, None].repeat(1, 32), ys.to(f.device)[:, None].repeat(1, 32)], 1))
+        del styles0, feats0, f
 
     def step():
         return invert_and_edit(imgs, e4e, g, clip, net, text, att, attention_layer=13)
@@ -431,7 +440,7 @@ def main():
                                 f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
                    "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
-                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None},
+                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "mask_mean": (float(mask.last.mean()) if hasattr(mask, "last") else None), "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None},
     }
     if timer is not None:
         s = timer.summary()
@@ -500,6 +509,7 @@ def main():
         dt3 = time.perf_counter() - t3
         out["config3"] = {"value": b3 * args.steps / dt3, "unit": "images/s", "ms_per_step": 1e3 * dt3 / args.steps, "batch": b3,
                           "final_loss": float(last3["loss"]), "stabilise_steps": n3, "hip_graph": graph3,
+                          "mask_mean": float(mask3.last.mean()) if hasattr(mask3, "last") else None,
                           "workload": "BASELINE configs[2]: FFHQ-1024 mapper step with the region-attention mask (cluster-pooled, "
                                       "thresholded, blurred; run_attention.py:754-884) blended at layer 13 + clip_loss + id_loss "
                                       "(IR-SE50), batch 8, 1 GPU; same as `bench.py --workload 3 --batch 8`"}

@@ -6,7 +6,7 @@
 //             Split-K partials are WRITTEN (one [M,N] slab per split), never added atomically: the consumer kernel
 //             (reduce + LayerNorm, LayerNorm backward, attention) sums them -- bit-reproducible, no memset, and it replaces
 //             the separate LayerNorm launch.  Operands stream global -> LDS by buffer_load...lds (16 B per lane) in a
-//             4-stage ring of 32-deep K-steps, raw row-major rows with an XOR swizzle of the 16-B quads chosen at the SOURCE
+//             2-stage ring (two workgroups per CU) of 32-deep K-steps, raw row-major rows with an XOR swizzle of the 16-B quads chosen at the SOURCE
 //             address (lane l fetches quad (l%8)^(l/8) of its row), so the MFMA operand fetch -- one ds_read_b128 per
 //             operand per 4 MFMAs -- is bank-conflict free.  One barrier per K-step; waits are vmcnt-counted per wave.
 //   reduce_ln_fwd    x = sum_s partial_s + bias + residual;  y = LayerNorm(x)      (one wave per row)
@@ -29,7 +29,7 @@ __device__ __forceinline__ float quick_gelu_grad2(float x) {
 
 // ------------------------------------------------------------------------------------------ gemm_fm
 #ifndef W2E_FM_STAGES
-#define W2E_FM_STAGES 4
+#define W2E_FM_STAGES 2  // 65 KB of LDS: two workgroups per CU hide each other's first-load and epilogue
 #endif
 constexpr int FM_WAVES = 7, FM_ROWS = 32 * FM_WAVES, FM_BN = 32, FM_BK = 32, FM_STAGES = W2E_FM_STAGES;
 constexpr int FM_SLOTS = 5;                                   // DMA wave-instructions per wave per K-step (7 x 5 = 35 >= 32)
@@ -640,11 +640,15 @@ extern "C" int w2e_gemm_fm_splits(int m, int n, int k, int allow_split) {
     for (int sp = 1; sp <= 16; ++sp) {
         const int per = (int)ceil_div(steps, sp);
         if (sp > 1 && (int)ceil_div(steps, per) != sp) continue;
-        if (sp > 1 && per < 4) break;
-        // time ~ rounds over the 256 CUs x (K-steps per slice + fixed prologue/epilogue in step units) + slab traffic
+        if (sp > 1 && per < 2) break;
+        // Measured model (microseconds, M <= 224, 2-stage ring = two workgroups per CU sharing its MFMA pipes): a K-step costs
+        // ~1.1 us per co-resident round of 256 workgroups, ~5 us of launch + first-load + epilogue, 0.7 us per 256 workgroups
+        // of scheduling, and every slab is one more pass for the consumer that sums them.
+        const double wgs = (double)(tiles * sp);
         const double rounds = (double)ceil_div(tiles * sp, 256);
-        const double cost = rounds * (per + 6.0) + (sp > 1 ? 0.5 * sp : 0.0);
-        if (sp == 1 || cost < best_cost * 0.97) best = sp, best_cost = cost;
+        double cost = rounds * per * 1.1 + 5.0 + 0.7 * wgs / 256.0 + 0.15 * sp;
+        if (wgs > 512.0) cost *= 1.1;  // a third round starts behind the first two
+        if (sp == 1 || cost < best_cost * 0.98) best = sp, best_cost = cost;
     }
     return best;
 }
