@@ -250,6 +250,22 @@ def _gen(size, cls=None):
     return freeze_conv_weights(g.to(DEV).eval())
 
 
+def test_style_codes_equal_the_generator_pass():
+    """Generator.style_codes: the W+ latent and the 26 S-space codes that forward(..., return_latents=True) returns, without
+    the synthesis pass (z, W and W+ inputs, truncation)."""
+    g = _gen(64)
+    gen = torch.Generator().manual_seed(11)
+    z, wp = torch.randn(3, 512, generator=gen).to(DEV), torch.randn(3, g.n_latent, 512, generator=gen).to(DEV)
+    mean = g.mean_latent(256)
+    for styles, kw in (([z], {}), ([z], {"truncation": 0.7, "truncation_latent": mean}), ([wp], {"input_is_latent": True})):
+        with torch.no_grad():
+            _, lat_ref, codes_ref = g(styles, return_latents=True, randomize_noise=False, **kw)
+            lat, codes = g.style_codes(styles, **kw)
+        assert torch.equal(lat, lat_ref) and len(codes) == len(codes_ref) == 2 * g.n_latent - 10 or len(codes) == len(codes_ref)
+        for a, b in zip(codes, codes_ref):
+            assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_generator16_golden_all_modes():
     from where2edit_amd.attention_model import Generator as AttGenerator
     g = golden("generator16")

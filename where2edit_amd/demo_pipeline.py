@@ -1,7 +1,8 @@
 """BASELINE configs[4], the inference pipeline of show_demo/try_demo.py:93-157 + utils_demo.py:142-157 as one function:
 
     256^2 image -> e4e (+ latent_avg)               -> W+ [B,18,512]                     (try_demo.py:98)
-    G(W+) with return_latents                       -> the 26 S-space codes              (:99-101)
+    G(W+) with return_latents                       -> the 26 S-space codes              (:99-101; here Generator.style_codes:
+                                                       the modulation affines only, no synthesis pass for a dropped image)
     G(S codes) with return_features                 -> img_orig + 26 activations (+ const input)   (:122-125)
     CLIP image features of img_orig                                                           (:123-124)
     Mapper(text (+) S codes, features)              -> new S codes + region mask          (utils_demo.py:152)
@@ -34,7 +35,10 @@ def invert_and_edit(images, e4e, g_ema, clip_loss, mapper, text_features, attent
     mask, the inverted W+ and the new S codes, and the CLIP image features before / after."""
     b = images.shape[0]
     latents = e4e(images)
-    _, latents, styles = g_ema([latents], input_is_latent=True, return_latents=True, randomize_noise=False)
+    if hasattr(g_ema, "style_codes"):  # the codes alone: the reference runs the whole generator here and drops the image
+        latents, styles = g_ema.style_codes([latents], input_is_latent=True)
+    else:
+        _, latents, styles = g_ema([latents], input_is_latent=True, return_latents=True, randomize_noise=False)
     img_orig, _, _, feats = g_ema([styles], input_is_latent=True, randomize_noise=False, return_features=True, input_is_stylespace=True)
     feats = list(feats) + [g_ema.input.input.repeat(b, 1, 1, 1)]
     feat_orig = clip_loss.model.encode_image(clip_loss.preprocess(img_orig))

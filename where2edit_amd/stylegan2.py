@@ -486,6 +486,18 @@ class Generator(nn.Module):
             return None
         return K.style_affine_all(latent, self._style_pack(plan))
 
+    def style_codes(self, styles, inject_index=None, truncation=1, truncation_latent=None, input_is_latent=False):
+        """(latent, the 26 S-space codes [B,1,C,1,1]) -- the second and third values of forward(..., return_latents=True)
+        (model.py:527-574) WITHOUT running the synthesis network: for callers that invert to W+ and only need the codes
+        (show_demo/try_demo.py:99-101 runs the whole generator for them and drops the image)."""
+        latent, _ = self._prepare(styles, inject_index, truncation, truncation_latent, input_is_latent, False, None, False)
+        plan = self._layers()
+        batch = latent.shape[0]
+        batched = self._batched_styles(latent, plan)
+        if batched is not None:
+            return latent, [s.view(batch, 1, s.shape[1], 1, 1) for s in batched]
+        return latent, [mod.conv._style(latent[:, widx], batch, False) for mod, _, widx, _ in plan]
+
     def _synthesis(self, latent, noise, input_is_stylespace, on_layer=None):
         batch_ref = latent[0] if input_is_stylespace else latent
         out = self.input(batch_ref)
