@@ -214,22 +214,30 @@ def self_launch(args):
     raise SystemExit(max(abs(rc) for rc in rcs))
 
 
-def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0):
+def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0, world=1, device=None):
     """Untimed full steps until the last `window` step times agree within `tol` ((max-min)/mean): a fresh box leaves its idle
     clocks, caches / allocator pools / lazily built packs settle.  Independent of --warmup, so the timed region starts at
-    steady state whatever the caller asks for (round 1 lost 10 % of its headline to a 5-step warm-up)."""
+    steady state whatever the caller asks for (round 1 lost 10 % of its headline to a 5-step warm-up).
+    With several ranks the decision to stop is taken TOGETHER (every step holds a collective: ranks that left the loop after
+    different numbers of steps would leave the last all-reduces of the slower ones without a partner): stop when every rank is
+    stable, or when any rank has hit a limit."""
     times = []
     t_begin = time.perf_counter()
-    while len(times) < max_steps and time.perf_counter() - t_begin < max_seconds:
+    while True:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         step_fn()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
         last = times[-window:]
-        if len(last) == window and (max(last) - min(last)) <= tol * (sum(last) / window):
-            return len(times), True
-    return len(times), False
+        stable = len(last) == window and (max(last) - min(last)) <= tol * (sum(last) / window)
+        limit = len(times) >= max_steps or time.perf_counter() - t_begin >= max_seconds
+        if world > 1:
+            flags = torch.tensor([1.0 if stable else 0.0, 0.0 if limit else 1.0], device=device)
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MIN)
+            stable, limit = bool(flags[0].item() == 1.0), bool(flags[1].item() == 0.0)
+        if stable or limit:
+            return len(times), stable
 
 
 def bench_config5(args, rank, world, device):
@@ -271,7 +279,7 @@ def bench_config5(args, rank, world, device):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    n_stab, ok = stabilise(step)
+    n_stab, ok = stabilise(step)  # (replicas: no collective inside a step, every rank may stop by itself)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -383,7 +391,7 @@ def main():
             graph_note = f"eager: capture failed ({type(e).__name__}: {e})"[:300]
             torch.cuda.synchronize()
     args.graph = use_graph
-    stab_steps, stab_ok = (0, False) if args.no_stabilise else stabilise(step_fn)
+    stab_steps, stab_ok = (0, False) if args.no_stabilise else stabilise(step_fn, world=world, device=device)
     for _ in range(args.warmup):
         step_fn()
     barrier()
