@@ -66,6 +66,12 @@ int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, i
                   int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout,
                   int act, const float* out_scale, const float* noise, const float* noise_w, const float* bias,
                   int channels, float slope, float gain, void* stream);
+/* The StyledConv backward of an up-sampling layer in one pass (op/fused_act.py:42-60 + the adjoint of Blur(pad=(1,1)),
+ * model.py:253-259): gt [planes, h+1, w+1] = adjoint 4x4 FIR (pad 2, un-flipped taps) of gpre = gy * gain * (y_fwd > 0 ? 1 : slope),
+ * and sums [planes,3] = (sum gpre * pre-activation, sum gpre * noise, sum gpre) as w2e_bias_act_bwd_reduce returns them; gpre is
+ * never written.  gy, y_fwd [planes, h, w]; noise [h*w] or NULL; w >= 256 and a multiple of 4; not in deterministic mode. */
+int w2e_blur_adjoint_actbwd(const float* gy, const float* y_fwd, const float* noise, const float* kern, float* gt, float* sums,
+                            int64_t planes, int h, int w, float slope, float gain, void* stream);
 
 /* ---- K3  bias (+noise) + leaky-relu * gain  (op/fused_act.py:23-39, model.py:285-290) -----
  * x viewed as [outer, channels, inner]; bias[channels] or NULL; noise[inner] or NULL with device

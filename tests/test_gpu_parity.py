@@ -660,6 +660,27 @@ def test_upfirdn_stream_dense_adjoint_equals_tile_kernel(h, w, separable, w2e_op
         assert_close(y, ref, 2e-6, f"stream dense {oh}x{ow}")
 
 
+@pytest.mark.parametrize("h,w,with_noise", [(128, 128, True), (130, 256, False), (65, 512, True)])
+def test_blur_adjoint_with_fused_activation_backward(h, w, with_noise, w2e_opt):
+    """w2e_blur_adjoint_actbwd (the StyledConv backward of a wide up-sampling layer in one pass): the same adjoint-blurred
+    pre-activation gradient and the same three per-plane sums as w2e_bias_act_bwd_reduce followed by the adjoint blur."""
+    from where2edit_amd import functional as K
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(9 * h + w)
+    b, c = 2, 5
+    gy, y = torch.randn(b, c, 2 * h, 2 * w, generator=g).to(DEV), torch.randn(b, c, 2 * h, 2 * w, generator=g).to(DEV)
+    noise = torch.randn(1, 1, 2 * h, 2 * w, generator=g).to(DEV) if with_noise else None
+    k4 = cu(seeded.fir_kernel(gain=1.0))
+    gpre, sums_ref = torch.empty_like(gy), torch.empty(b, c, 3, device=DEV)
+    call("w2e_bias_act_bwd_reduce", ptr(gy), ptr(y), ptr(noise), ptr(gpre), ptr(sums_ref), b, c, 4 * h * w, 0.2, 2 ** 0.5, stream_ptr())
+    gt_ref = K._upfirdn2d_raw(gpre, k4, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
+    gt, sums = torch.full((b, c, 2 * h + 1, 2 * w + 1), float("nan"), device=DEV), torch.full((b, c, 3), float("nan"), device=DEV)
+    call("w2e_blur_adjoint_actbwd", ptr(gy), ptr(y), ptr(noise), ptr(k4), ptr(gt), ptr(sums), b * c, 2 * h, 2 * w, 0.2, 2 ** 0.5, stream_ptr())
+    assert_close(gt, gt_ref, 2e-6, "adjoint-blurred pre-activation gradient")
+    for i, name in enumerate(("sum gpre*pre", "sum gpre*noise", "sum gpre")):
+        assert_close(sums[..., i] + 1.0, sums_ref[..., i] + 1.0, 2e-5, name)  # (+1: a sum near 0 is compared absolutely)
+
+
 @pytest.mark.parametrize("cin,h,with_skip,prefix", [(32, 64, True, 0), (12, 18, False, 0), (512, 8, True, 1), (64, 128, True, 2)])
 def test_to_rgb_styled_equals_per_sample_weight(cin, h, with_skip, prefix):
     """w2e_torgb_styled_*: the kernels form scale*W[c,i]*style[b,i] themselves and return the style gradient; same image and

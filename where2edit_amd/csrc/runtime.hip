@@ -106,6 +106,8 @@ int w2e_get_option(const char* name, int* value) {
     if (!strcmp(name, "conv_precision")) *value = o.conv_precision;
     else if (!strcmp(name, "deterministic")) *value = o.deterministic;
     else if (!strcmp(name, "tune_cfg")) *value = o.tune_cfg;
+    else if (!strcmp(name, "tune_fuse")) *value = o.tune_fuse;
+    else if (!strcmp(name, "tune_blur")) *value = o.tune_blur;
     else if (!strcmp(name, "tuning_build")) {
 #ifdef W2E_TUNING
         *value = 1;

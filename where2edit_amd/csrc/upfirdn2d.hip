@@ -29,6 +29,10 @@ struct UpfirdnParams {
     const float* bias;
     int channels;
     float slope, gain;
+    // fused activation backward (upfirdn_stream4_kernel<..., ACTBWD>): x is the gradient w.r.t. the activated output, y_fwd that
+    // output; the filtered quantity is x * gain * (y_fwd > 0 ? 1 : slope), and its three per-plane sums are added to sums[plane][3]
+    const float* y_fwd;
+    float* sums;
 };
 
 __device__ __forceinline__ float epilogue(const UpfirdnParams& p, float v, int64_t plane, int oy, int ox, float nw) {
@@ -336,8 +340,14 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
 //  * Dense source with an odd out_w (in_w + 1): the lane owning the last full group also computes the single last column.
 constexpr int SR = 64;  // strip rows per wave (3 halo rows re-read per strip: 4.7 %)
 
-template <bool ACT, bool PLANAR>
+//  * ACTBWD (dense source, the StyledConv backward of an up-sampling layer): the source is read together with the layer's
+//    forward output and the activation backward gpre = g * gain * (out > 0 ? 1 : slope) is applied to the window on the way
+//    (w2e_bias_act_bwd_reduce's arithmetic); the three per-plane sums of that kernel (gpre * pre-activation, gpre * noise, gpre)
+//    are accumulated over the rows and columns the lane OWNS (not its halo) and added to sums[plane][3] -- gpre itself is never
+//    written: 3 tensor passes instead of 5.
+template <bool ACT, bool PLANAR, bool ACTBWD = false>
 __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, int col_groups, int strips) {
+    static_assert(!ACTBWD || (!ACT && !PLANAR), "the fused activation backward is the dense adjoint form");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -404,7 +414,12 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
         f32x2 q[NP];  // PLANAR: the pairs as loaded.  Dense: q[0] = (w0,w1), then the 16-byte group d4 = w2..w5 and d1 = w6;
         f32x4 d4;     //         the three pairs that straddle those loads are put together where they are consumed
         float d1;
+        f32x2 yq;     // ACTBWD: the forward output at the same 7 columns
+        f32x4 y4;
+        float y1;
     };
+    const __amdgpu_buffer_rsrc_t ryf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACTBWD ? p.y_fwd + (int64_t)plane * plane_stride : p.x),
+                                                                       (short)0, ACTBWD ? (int)(plane_stride * 4) : 0, 0x00020000);
     // (`need` false: a row nobody will consume -- the load is still ISSUED, against the empty descriptor, so that every path
     // through the loop has the same number of loads in flight and the compiler's counter waits stay partial)
     auto load_row = [&](int r, Win& w, bool need) __attribute__((always_inline)) {
@@ -428,7 +443,41 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
             w.q[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vd[0], so, 0));
             w.d4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vd[1], so, 0));
             w.d1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vd[2], so, 0));
+            if (ACTBWD) {
+                const __amdgpu_buffer_rsrc_t ry2 = ok ? ryf : rzero;
+                w.yq = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ry2, vd[0], so, 0));
+                w.y4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry2, vd[1], so, 0));
+                w.y1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry2, vd[2], so, 0));
+            }
         }
+    };
+    // ACTBWD: window of gradients -> window of pre-activation gradients, and this lane's share of the three sums (its own 4
+    // columns w2..w5 of the rows its strip owns; `own` is uniform)
+    float s_pre = 0.f, s_noise = 0.f, s_sum = 0.f;
+    const float inv_pos = 1.f / p.gain, inv_neg = 1.f / (p.gain * p.slope);
+    auto act_bwd = [&](Win& w, const f32x4 nz, bool own) __attribute__((always_inline)) {
+        if (!ACTBWD) return;
+        const float ya[7] = {w.yq[0], w.yq[1], w.y4[0], w.y4[1], w.y4[2], w.y4[3], w.y1};
+        float ga[7] = {w.q[0][0], w.q[0][1], w.d4[0], w.d4[1], w.d4[2], w.d4[3], w.d1};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ga[i] = ga[i] * p.gain * (ya[i] > 0.f ? 1.f : p.slope);
+        if (own) {
+#pragma unroll
+            for (int i = 2; i < 6; ++i) {
+                s_pre += ga[i] * (ya[i] * (ya[i] > 0.f ? inv_pos : inv_neg));
+                s_noise += ga[i] * nz[i - 2];
+                s_sum += ga[i];
+            }
+        }
+        w.q[0] = f32x2{ga[0], ga[1]}, w.d4 = f32x4{ga[2], ga[3], ga[4], ga[5]}, w.d1 = ga[6];
+    };
+    // noise of SOURCE row r at this lane's own columns (ACTBWD: the s_noise term); travels with the row's window
+    const __amdgpu_buffer_rsrc_t rnb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((ACTBWD && p.noise) ? p.noise : p.x), (short)0,
+                                                                       (ACTBWD && p.noise) ? (int)((unsigned)(p.in_h * p.in_w) * 4u) : 0, 0x00020000);
+    auto load_noise_src = [&](int r, bool need) __attribute__((always_inline)) {
+        if (!ACTBWD) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = need && r >= 0 && r < p.in_h;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rnb : rzero, vd[1], ok ? (unsigned)(r * p.in_w) * 4u : 0u, 0));
     };
     auto fix_row = [&](Win& w) __attribute__((always_inline)) {  // only in waves that hold an edge lane
         if (!wave_fix) return;
@@ -542,32 +591,44 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
     // output row y0 + i, whose noise row travels with it (issued BEFORE that window's loads: the counter waits stay partial)
     const int r0 = y0 - p.pad_y0;
     Win w0, w1, w2, w3;
-    f32x4 n0, n1, n2, n3;
-    load_row(r0, w0, true), load_row(r0 + 1, w1, true), load_row(r0 + 2, w2, true);
-    n0 = load_noise(y0, true), load_row(r0 + 3, w3, true);
+    f32x4 n0, n1, n2, n3;      // ACT: noise of the output row a window closes
+    f32x4 m0, m1, m2, m3;      // ACTBWD: noise of the SOURCE row of window w0..w3 (own columns)
+    m0 = load_noise_src(r0, true), load_row(r0, w0, true);
+    m1 = load_noise_src(r0 + 1, true), load_row(r0 + 1, w1, true);
+    m2 = load_noise_src(r0 + 2, true), load_row(r0 + 2, w2, true);
+    n0 = load_noise(y0, true), m3 = load_noise_src(r0 + 3, true), load_row(r0 + 3, w3, true);
+    // a strip OWNS the source rows y0 .. y0+SR-1 = windows k = pad_y0 .. pad_y0+SR-1 (ACTBWD runs with pad_y0 = 2): the sums count
+    // every source element exactly once although the halo rows are read by two strips
     // prologue: the first three source rows only open output rows >= y0  (kernel rows a <= k)
-    fix_row(w0), scatter(w0, 0, 0);
-    n1 = load_noise(y0 + 1, true), load_row(r0 + 4, w0, true);
-    fix_row(w1), scatter(w1, 1, 1);
-    n2 = load_noise(y0 + 2, true), load_row(r0 + 5, w1, true);
-    fix_row(w2), scatter(w2, 2, 2);
-    n3 = load_noise(y0 + 3, true), load_row(r0 + 6, w2, true);
+    fix_row(w0), act_bwd(w0, m0, p.pad_y0 <= 0), scatter(w0, 0, 0);
+    n1 = load_noise(y0 + 1, true), m0 = load_noise_src(r0 + 4, true), load_row(r0 + 4, w0, true);
+    fix_row(w1), act_bwd(w1, m1, p.pad_y0 <= 1), scatter(w1, 1, 1);
+    n2 = load_noise(y0 + 2, true), m1 = load_noise_src(r0 + 5, true), load_row(r0 + 5, w1, true);
+    fix_row(w2), act_bwd(w2, m2, p.pad_y0 <= 2), scatter(w2, 2, 2);
+    n3 = load_noise(y0 + 3, true), m2 = load_noise_src(r0 + 6, true), load_row(r0 + 6, w2, true);
     int rows = p.out_h - y0;  // output rows of this strip
     rows = rows < SR ? rows : SR;
+    const int k_own_end = p.pad_y0 + SR;  // windows k >= this belong to the next strip
     for (int i = 0; i < rows; i += 4) {
         const bool more = i + 4 < rows;  // (the last group needs source rows up to r0 + i + 6 only: already in flight)
-        fix_row(w3), scatter(w3, 3, 3);
+        fix_row(w3), act_bwd(w3, m3, i + 3 < k_own_end), scatter(w3, 3, 3);
         emit(y0 + i, 0, n0);
-        n0 = load_noise(y0 + i + 4, more), load_row(r0 + 7 + i, w3, more);
-        fix_row(w0), scatter(w0, 0, 3);
+        n0 = load_noise(y0 + i + 4, more), m3 = load_noise_src(r0 + 7 + i, more), load_row(r0 + 7 + i, w3, more);
+        fix_row(w0), act_bwd(w0, m0, i + 4 < k_own_end), scatter(w0, 0, 3);
         emit(y0 + i + 1, 1, n1);
-        n1 = load_noise(y0 + i + 5, more), load_row(r0 + 8 + i, w0, more);
-        fix_row(w1), scatter(w1, 1, 3);
+        n1 = load_noise(y0 + i + 5, more), m0 = load_noise_src(r0 + 8 + i, more), load_row(r0 + 8 + i, w0, more);
+        fix_row(w1), act_bwd(w1, m1, i + 5 < k_own_end), scatter(w1, 1, 3);
         emit(y0 + i + 2, 2, n2);
-        n2 = load_noise(y0 + i + 6, more), load_row(r0 + 9 + i, w1, more);
-        fix_row(w2), scatter(w2, 2, 3);
+        n2 = load_noise(y0 + i + 6, more), m1 = load_noise_src(r0 + 9 + i, more), load_row(r0 + 9 + i, w1, more);
+        fix_row(w2), act_bwd(w2, m2, i + 6 < k_own_end), scatter(w2, 2, 3);
         emit(y0 + i + 3, 3, n3);
-        n3 = load_noise(y0 + i + 7, more), load_row(r0 + 10 + i, w2, more);
+        n3 = load_noise(y0 + i + 7, more), m2 = load_noise_src(r0 + 10 + i, more), load_row(r0 + 10 + i, w2, more);
+    }
+    if (ACTBWD) {  // one atomic per wave and sum (the three sums of a plane are zeroed by the host before the launch)
+        float t0 = s_pre, t1 = s_noise, t2 = s_sum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t0 += __shfl_xor(t0, off, 64), t1 += __shfl_xor(t1, off, 64), t2 += __shfl_xor(t2, off, 64);
+        if (lane == 0) atomicAdd(p.sums + (int64_t)plane * 3, t0), atomicAdd(p.sums + (int64_t)plane * 3 + 1, t1), atomicAdd(p.sums + (int64_t)plane * 3 + 2, t2);
     }
 }
 
@@ -681,7 +742,7 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
                 "upfirdn2d: the phase-planar input layout is implemented for the 4x4, up=down=1 tile kernel only");
     const int tune = options().tune_blur;
     UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip, tune, in_layout,
-                    act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain};
+                    act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     if (up == 1 && down == 1 && out_w >= 32 && kh <= MAX_TILE_K && kw <= MAX_TILE_K) {
         const int tiles_x = (int)ceil_div(out_w, TW), tiles_y = (int)ceil_div(out_h, TH);
@@ -740,3 +801,30 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     W2E_LAUNCH_CHECK("upfirdn2d");
     return 0;
 }
+
+extern "C" int w2e_blur_adjoint_actbwd(const float* gy, const float* y_fwd, const float* noise, const float* kern, float* gt,
+                                       float* sums, int64_t planes, int h, int w, float slope, float gain, void* stream) {
+    W2E_REQUIRE(gy && y_fwd && kern && gt && sums, "blur_adjoint_actbwd: null tensor");
+    W2E_REQUIRE(planes >= 0 && h > 0 && w >= 256 && (w & 3) == 0, "blur_adjoint_actbwd: needs a width >= 256 that is a multiple of 4 (got %dx%d)", h, w);
+    W2E_REQUIRE(((uintptr_t)gy & 15) == 0 && ((uintptr_t)y_fwd & 15) == 0 && ((uintptr_t)gt & 15) == 0 && (!noise || ((uintptr_t)noise & 15) == 0),
+                "blur_adjoint_actbwd: tensors must be 16-byte aligned");
+    W2E_REQUIRE(gain > 0.f && slope > 0.f, "blur_adjoint_actbwd: gain and slope must be positive");
+    W2E_REQUIRE(!options().deterministic, "blur_adjoint_actbwd: the sums are joined with fp32 atomics (use w2e_bias_act_bwd_reduce + w2e_upfirdn2d in deterministic mode)");
+    if (planes == 0) return 0;
+    W2E_REQUIRE((int64_t)(h + 1) * (w + 1) < ((int64_t)1 << 29), "blur_adjoint_actbwd: plane too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (zero_async(sums, sizeof(float) * 3 * (size_t)planes, s) != hipSuccess) {
+        set_error("blur_adjoint_actbwd: zero fill failed");
+        return 2;
+    }
+    UpfirdnParams p{gy, kern, gt, planes, h, w, h + 1, w + 1, 4, 4, 1, 1, 2, 2, 0, options().tune_blur & 7, 0,
+                    0, nullptr, noise, nullptr, nullptr, 1, slope, gain, y_fwd, sums};
+    const int lanes = w / 4;  // out_w = w + 1: the single last column rides on the last full group
+    const int col_groups = (int)ceil_div(lanes, 64), strips = (int)ceil_div(h + 1, SR);
+    const int64_t waves = planes * col_groups * strips;
+    W2E_REQUIRE(waves < ((int64_t)1 << 31), "blur_adjoint_actbwd: tensor too large");
+    upfirdn_stream4_kernel<false, false, true><<<(unsigned)ceil_div(waves, 4), 256, 0, s>>>(p, col_groups, strips);
+    W2E_LAUNCH_CHECK("blur_adjoint_actbwd");
+    return 0;
+}
+

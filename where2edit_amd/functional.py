@@ -268,11 +268,21 @@ class _StyledConv(torch.autograd.Function):
         gx_out = gx_full[n_skip:] if n_skip else None
         gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device)
         g_bias = g_nw = sums = dz = None
+        blurred = False
         if fuse_act:
-            gpre = torch.empty_like(out)
             sums = torch.empty((b, cout, 3), device=x.device, dtype=torch.float32)
-            call("w2e_bias_act_bwd_reduce", ptr(gout), ptr(out), ptr(noise), ptr(gpre), ptr(sums), b, cout, oh * ow,
-                 0.2, SQRT2, stream_ptr())
+            if (upsample and ow >= 256 and ow % 4 == 0 and tuple(blur_kernel.shape) == (4, 4) and not _lib.get_option("deterministic")
+                    and _lib.get_option("tune_fuse") != 0):  # (tune_fuse = 0: the two-kernel form, for comparison)
+                # wide up-sampling layers: activation backward, its three reductions and the adjoint blur in ONE pass over
+                # (gout, out) -- the pre-activation gradient is never written (3 tensor passes instead of 5)
+                gpre = torch.empty((b, cout, oh + 1, ow + 1), device=x.device, dtype=torch.float32)
+                call("w2e_blur_adjoint_actbwd", ptr(gout), ptr(out), ptr(noise), ptr(blur_kernel), ptr(gpre), ptr(sums), b * cout, oh, ow,
+                     0.2, SQRT2, stream_ptr())
+                blurred = True
+            else:
+                gpre = torch.empty_like(out)
+                call("w2e_bias_act_bwd_reduce", ptr(gout), ptr(out), ptr(noise), ptr(gpre), ptr(sums), b, cout, oh * ow,
+                     0.2, SQRT2, stream_ptr())
             if bias is not None and ctx.needs_input_grad[5]:
                 g_bias = sums[..., 2].sum(0)
             if noise is not None and ctx.needs_input_grad[4]:
@@ -281,7 +291,7 @@ class _StyledConv(torch.autograd.Function):
             gpre = gout
             if d is not None:
                 dz = (gout * out).sum((2, 3))
-        if upsample:
+        if upsample and not blurred:
             # adjoint of Blur(pad=(1,1)) back onto the (2h+1)x(2w+1) transposed-conv grid, then the
             # stride-2 conv that is the adjoint of conv_transpose2d
             gpre = _upfirdn2d_raw(gpre, blur_kernel, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
