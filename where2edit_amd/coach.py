@@ -101,7 +101,7 @@ class Coach:
                 both, lat, _ = dec([torch.cat([w.detach(), w_hat])], input_is_latent=True, return_latents=True, randomize_noise=False,
                                    truncation=1)
             self._x_ready = None
-            return both[:n].detach(), both[n:], lat[n:]
+            return both[:n].detach(), K.tail_rows(both, n), lat[n:]
         main = torch.cuda.current_stream()
         if self._side is not None and not self._side_primed:
             # the decoder's derived-weight caches (conv packs, wsq, stacked affines) are built lazily by the first pass:

@@ -690,6 +690,40 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpfirdnParams p, int 
     }
 }
 
+// 4x4 taps, up = 1, any down (the adjoint of the RGB-skip Upsample: [B,3,h,w] -> [B,3,h/2,w/2]): one output per thread, the 16
+// source values fetched by 16 independent buffer loads (out-of-image taps carry an out-of-range offset and read 0: no branches),
+// all in flight before the first FMA.  The tensors are small (3 channels): the launch is latency-bound, not bandwidth-bound.
+__global__ __launch_bounds__(256) void upfirdn_down4_kernel(UpfirdnParams p, int64_t total) {
+    float kr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kr[i] = p.flip ? p.kern[15 - i] : p.kern[i];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), (short)0, (int)(p.planes * p.in_h * p.in_w * 4), 0x00020000);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int ox = (int)(e % p.out_w);
+    const int64_t t = e / p.out_w;
+    const int oy = (int)(t % p.out_h);
+    const int plane = (int)(t / p.out_h);
+    const int iy0 = oy * p.down - p.pad_y0, ix0 = ox * p.down - p.pad_x0;
+    float v[16];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const int iy = iy0 + ky;
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int ix = ix0 + kx;
+            const bool ok = row_ok && ix >= 0 && ix < p.in_w;
+            const unsigned off = ok ? (unsigned)((plane * p.in_h + iy) * p.in_w + ix) * 4u : 0x80000000u;
+            v[ky * 4 + kx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += kr[i] * v[i];
+    p.y[e] = acc;
+}
+
 __global__ void upfirdn_generic_kernel(UpfirdnParams p, int64_t total) {
     __shared__ float kbuf[MAXK * MAXK];
     for (int i = threadIdx.x; i < p.kh * p.kw; i += blockDim.x) {
@@ -795,6 +829,8 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
         } else {
             upfirdn_tile_kernel<<<grid, 256, lds, s>>>(p, tiles_x, tiles_y, magic);
         }
+    } else if (up == 1 && kh == 4 && kw == 4 && !act && !in_layout && planes * in_h * in_w < ((int64_t)1 << 29) && total < ((int64_t)1 << 31)) {
+        upfirdn_down4_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, s>>>(p, total);
     } else {
         upfirdn_generic_kernel<<<stream_grid(total, 256), 256, 0, s>>>(p, total);
     }

@@ -36,6 +36,28 @@ class nograd_prefix:
         _NOGRAD_PREFIX = self.prev
 
 
+class _TailRows(torch.autograd.Function):
+    """x[n:] of a batch whose first n rows carry no gradient (the merged generator pass): the backward hands the producer a
+    full-batch buffer whose tail holds the gradient and whose first n rows are unwritten -- every generator node slices them off
+    (`nograd_prefix`) -- instead of autograd's zero-fill of the whole batch + copy (SliceBackward)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.full = n, x.shape[0]
+        return x[n:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        out = torch.empty((ctx.full,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+        out[ctx.n:].copy_(g)
+        return out, None
+
+
+def tail_rows(x, n):
+    return _TailRows.apply(x, n)
+
+
 def _zeros_with_tail(full, n, tail_shape, device):
     """-> (buf, tail): a zeroed [full, *tail_shape] fp32 buffer and its rows [n:] (a contiguous view) for a kernel to write:
     the [B,C]-sized gradients of a node inside `nograd_prefix` in one fill, no concatenation."""
