@@ -7,8 +7,8 @@ path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
 if len(sys.argv) > 2 and sys.argv[2] != "auto":
     steps = float(sys.argv[2])
-else:  # every mapper step launches bias_act_bwd_reduce exactly 17 times (one per StyledConv of the 1024^2 generator's backward)
-    steps = sum(int(r["Calls"]) for r in rows if "bias_act_bwd_reduce" in r["Name"]) / 17.0 or 1.0
+else:  # every mapper step launches the CLIP preprocessing backward exactly once (one CLIP loss per step, whatever the workload)
+    steps = float(sum(int(r["Calls"]) for r in rows if "clip_preproc_bwd" in r["Name"])) or 1.0
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 print(f"# {path}\n# total kernel time {tot / steps / 1e6:.3f} ms/step over {steps:g} steps")
 fam = {}

@@ -298,8 +298,11 @@ class _StyledConv(torch.autograd.Function):
                 # wide up-sampling layers: activation backward, its three reductions and the adjoint blur in ONE pass over
                 # (gout, out) -- the pre-activation gradient is never written (3 tensor passes instead of 5)
                 gpre = torch.empty((b, cout, oh + 1, ow + 1), device=x.device, dtype=torch.float32)
+                sp = profiling.span("upfirdn2d", 4.0 * b * cout * (2 * oh * ow + (oh + 1) * (ow + 1)))  # algorithmic bytes: gout + out + gT
                 call("w2e_blur_adjoint_actbwd", ptr(gout), ptr(out), ptr(noise), ptr(blur_kernel), ptr(gpre), ptr(sums), b * cout, oh, ow,
                      0.2, SQRT2, stream_ptr())
+                if sp is not None:
+                    sp.end()
                 blurred = True
             else:
                 gpre = torch.empty_like(out)
