@@ -159,6 +159,14 @@ int w2e_torgb_styled_fwd(const float* x, const float* wsc, const float* style, c
                          const float* upk, float* y, int batch, int cin, int h, int w, void* stream);
 int w2e_torgb_styled_bwd(const float* x, const float* wsc, const float* style, const float* gy, const float* gx_acc,
                          float* gx, float* gstyle, int batch, int cin, int h, int w, void* stream);
+/* ToRGB backward fused with the activation backward of the StyledConv that produced x (x = its output, model.py:334-340 feeding
+ * :353): instead of gx it writes gpre = gx * gain * (x > 0 ? 1 : slope), and sums3 [B,cin,3] = the three per-(b, channel) sums of
+ * w2e_bias_act_bwd_reduce (gpre * pre-activation, gpre * noise, gpre), so that layer needs no separate activation-backward pass.
+ * style NULL: wmod [B,3,cin], gw [B,3,cin]; style [B,cin]: wmod = the shared [3,cin] weight, gw = the style gradient [B,cin].
+ * gx_acc (the gradient that reached x through its other consumer) and noise [h*w] may be NULL. */
+int w2e_torgb_bwd_actbwd(const float* x, const float* wmod, const float* style, const float* gy, const float* gx_acc,
+                         const float* noise, float* gpre, float* gw, float* sums3, int batch, int cin, int h, int w, float slope,
+                         float gain, void* stream);
 
 /* ---- K5  CLIP preprocessing  (criteria/clip_loss.py:11-12,15) ------------------------------
  * AvgPool2d(size/32)(Upsample(x7, nearest)(img)) in closed form: [planes,size,size] -> [planes,224,224];

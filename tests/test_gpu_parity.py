@@ -660,6 +660,36 @@ def test_upfirdn_stream_dense_adjoint_equals_tile_kernel(h, w, separable, w2e_op
         assert_close(y, ref, 2e-6, f"stream dense {oh}x{ow}")
 
 
+@pytest.mark.parametrize("cin,h,styled,with_acc,with_noise", [(32, 64, True, True, True), (12, 18, False, False, True), (512, 8, True, True, False),
+                                                               (64, 128, False, True, True)])
+def test_torgb_backward_with_fused_activation_backward(cin, h, styled, with_acc, with_noise):
+    """w2e_torgb_bwd_actbwd: the ToRGB input gradient with the producing StyledConv's activation backward applied and that
+    layer's three sums, against w2e_torgb_bwd_acc / w2e_torgb_styled_bwd followed by w2e_bias_act_bwd_reduce."""
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(13 * cin + h)
+    b = 3
+    x = torch.randn(b, cin, h, h, generator=g).to(DEV)
+    gy = torch.randn(b, 3, h, h, generator=g).to(DEV)
+    acc = torch.randn(b, cin, h, h, generator=g).to(DEV) if with_acc else None
+    noise = torch.randn(h * h, generator=g).to(DEV) if with_noise else None
+    style = torch.randn(b, cin, generator=g).to(DEV) if styled else None
+    wmod = (torch.randn(3, cin, generator=g) * 0.2).to(DEV) if styled else (torch.randn(b, 3, cin, generator=g) * 0.2).to(DEV)
+    gx, gw_ref = torch.empty_like(x), torch.empty((b, cin) if styled else (b, 3, cin), device=DEV)
+    if styled:
+        call("w2e_torgb_styled_bwd", ptr(x), ptr(wmod), ptr(style), ptr(gy), ptr(acc), ptr(gx), ptr(gw_ref), b, cin, h, h, stream_ptr())
+    else:
+        call("w2e_torgb_bwd_acc", ptr(x), ptr(wmod), ptr(gy), ptr(acc), ptr(gx), ptr(gw_ref), b, cin, h, h, stream_ptr())
+    gpre_ref, sums_ref = torch.empty_like(x), torch.empty(b, cin, 3, device=DEV)
+    call("w2e_bias_act_bwd_reduce", ptr(gx), ptr(x), ptr(noise), ptr(gpre_ref), ptr(sums_ref), b, cin, h * h, 0.2, 2 ** 0.5, stream_ptr())
+    gpre, gw, sums = torch.full_like(x, float("nan")), torch.full_like(gw_ref, float("nan")), torch.full((b, cin, 3), float("nan"), device=DEV)
+    call("w2e_torgb_bwd_actbwd", ptr(x), ptr(wmod), ptr(style), ptr(gy), ptr(acc), ptr(noise), ptr(gpre), ptr(gw), ptr(sums), b, cin, h, h,
+         0.2, 2 ** 0.5, stream_ptr())
+    assert_close(gpre, gpre_ref, 2e-6, "pre-activation gradient")
+    assert_close(gw, gw_ref, 1e-5, "weight / style gradient")
+    scale = sums_ref.abs().max()
+    assert float((sums - sums_ref).abs().max()) <= 2e-5 * float(scale), "sums"
+
+
 @pytest.mark.parametrize("h,w,with_noise", [(128, 128, True), (130, 256, False), (65, 512, True)])
 def test_blur_adjoint_with_fused_activation_backward(h, w, with_noise, w2e_opt):
     """w2e_blur_adjoint_actbwd (the StyledConv backward of a wide up-sampling layer in one pass): the same adjoint-blurred

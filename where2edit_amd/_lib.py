@@ -34,6 +34,7 @@ _PROTOS = {
     "w2e_torgb_bwd_acc": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_torgb_styled_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_torgb_styled_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_torgb_bwd_actbwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "w2e_clip_preproc_fwd": (_I, [_P, _P, _L, _I, _P]),
     "w2e_clip_preproc_bwd": (_I, [_P, _P, _L, _I, _P]),
     "w2e_id_preproc_fwd": (_I, [_P, _P, _L, _I, _P]),

@@ -115,12 +115,17 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // same pixel range so their gy reads share L1.  ACC: gx = gx_acc + (that sum) -- the gradient that reached x through its
 // other consumer (the next conv) is folded in here instead of by a separate elementwise add of two activation-sized tensors.
 // `style` != null (see the forward): wmod is [3][cin] and gwmod is the STYLE gradient [B][cin] = sum_c wmod[c,i]*(that sum).
-template <int V, bool ACC>
+// ACTB: x is the OUTPUT of the fused StyledConv that feeds this ToRGB (bias + noise + LeakyReLU * gain, model.py:334-340), and what
+// that layer's backward needs is not gx but gpre = gx * gain * (x > 0 ? 1 : slope) together with the three per-(b, channel) sums
+// of w2e_bias_act_bwd_reduce -- computed here, on the value that is in a register anyway: the layer's separate activation
+// backward pass (read gx, read x, write gpre) disappears.
+template <int V, bool ACC, bool ACTB>
 __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wmod,
                                                         const float* __restrict__ style,
                                                         const float* __restrict__ gy, const float* __restrict__ gx_acc,
                                                         float* __restrict__ gx, float* __restrict__ gwmod, int cin,
-                                                        int64_t HW, int splits, int64_t per_split) {
+                                                        int64_t HW, int splits, int64_t per_split,
+                                                        const float* __restrict__ noise, float* __restrict__ sums3, float slope, float gain) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int split = blockIdx.x % splits;
     const int i = (blockIdx.x / splits) * 4 + wave;
@@ -140,6 +145,14 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
     const float* g0 = gy + (int64_t)b * 3 * HW;
     const int64_t lo = split * per_split, hi = (lo + per_split < HW) ? lo + per_split : HW;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float t_pre = 0.f, t_noise = 0.f, t_sum = 0.f;  // ACTB
+    const float inv_pos = 1.f / gain, inv_neg = 1.f / (gain * slope);
+    auto act_bwd = [&](float r, float xval, float nz) __attribute__((always_inline)) {
+        const bool pos = xval > 0.f;
+        const float g = r * gain * (pos ? 1.f : slope);
+        t_pre += g * (xval * (pos ? inv_pos : inv_neg)), t_noise += g * nz, t_sum += g;
+        return g;
+    };
     if (V == 4) {
 #pragma unroll 2
         for (int64_t p = lo + lane * 4; p < hi; p += 256) {
@@ -147,6 +160,8 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
             const float4 a = *reinterpret_cast<const float4*>(g0 + p);
             const float4 bb = *reinterpret_cast<const float4*>(g0 + HW + p);
             const float4 c = *reinterpret_cast<const float4*>(g0 + 2 * HW + p);
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ACTB && noise) nz = *reinterpret_cast<const float4*>(noise + p);
             float4 r;
             r.x = w0 * a.x + w1 * bb.x + w2 * c.x;
             r.y = w0 * a.y + w1 * bb.y + w2 * c.y;
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
                 const float4 av = *reinterpret_cast<const float4*>(ap + p);
                 r.x += av.x, r.y += av.y, r.z += av.z, r.w += av.w;
             }
+            if (ACTB) r.x = act_bwd(r.x, xv.x, nz.x), r.y = act_bwd(r.y, xv.y, nz.y), r.z = act_bwd(r.z, xv.z, nz.z), r.w = act_bwd(r.w, xv.w, nz.w);
             *reinterpret_cast<float4*>(gp + p) = r;
             s0 += xv.x * a.x + xv.y * a.y + xv.z * a.z + xv.w * a.w;
             s1 += xv.x * bb.x + xv.y * bb.y + xv.z * bb.z + xv.w * bb.w;
@@ -164,8 +180,18 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict_
     } else {
         for (int64_t p = lo + lane; p < hi; p += 64) {
             const float xv = xp[p], a = g0[p], bb = g0[HW + p], c = g0[2 * HW + p];
-            gp[p] = w0 * a + w1 * bb + w2 * c + (ACC ? ap[p] : 0.f);
+            float r = w0 * a + w1 * bb + w2 * c + (ACC ? ap[p] : 0.f);
+            if (ACTB) r = act_bwd(r, xv, noise ? noise[p] : 0.f);
+            gp[p] = r;
             s0 += xv * a, s1 += xv * bb, s2 += xv * c;
+        }
+    }
+    if (ACTB) {
+        t_pre = wave_sum64(t_pre), t_noise = wave_sum64(t_noise), t_sum = wave_sum64(t_sum);
+        if (lane == 0) {
+            float* d3 = sums3 + ((int64_t)b * cin + i) * 3;
+            if (splits == 1) d3[0] = t_pre, d3[1] = t_noise, d3[2] = t_sum;
+            else atomicAdd(d3, t_pre), atomicAdd(d3 + 1, t_noise), atomicAdd(d3 + 2, t_sum);
         }
     }
     s0 = wave_sum64(s0), s1 = wave_sum64(s1), s2 = wave_sum64(s2);
@@ -231,7 +257,8 @@ extern "C" int w2e_torgb_styled_fwd(const float* x, const float* wsc, const floa
 }
 
 static int torgb_bwd_impl(const float* x, const float* wmod, const float* style, const float* gy, const float* gx_acc,
-                          float* gx, float* gwmod, int batch, int cin, int h, int w, void* stream);
+                          float* gx, float* gwmod, int batch, int cin, int h, int w, void* stream, bool actb = false,
+                          const float* noise = nullptr, float* sums3 = nullptr, float slope = 0.f, float gain = 1.f);
 
 extern "C" int w2e_torgb_bwd(const float* x, const float* wmod, const float* gy, float* gx, float* gwmod, int batch,
                              int cin, int h, int w, void* stream) {
@@ -250,8 +277,17 @@ extern "C" int w2e_torgb_styled_bwd(const float* x, const float* wsc, const floa
     return torgb_bwd_impl(x, wsc, style, gy, gx_acc, gx, gstyle, batch, cin, h, w, stream);
 }
 
+extern "C" int w2e_torgb_bwd_actbwd(const float* x, const float* wmod, const float* style, const float* gy, const float* gx_acc,
+                                    const float* noise, float* gpre, float* gw, float* sums3, int batch, int cin, int h, int w,
+                                    float slope, float gain, void* stream) {
+    W2E_REQUIRE(sums3, "torgb_bwd_actbwd: null sums");
+    W2E_REQUIRE(gain > 0.f && slope > 0.f, "torgb_bwd_actbwd: gain and slope must be positive");
+    return torgb_bwd_impl(x, wmod, style, gy, gx_acc, gpre, gw, batch, cin, h, w, stream, true, noise, sums3, slope, gain);
+}
+
 static int torgb_bwd_impl(const float* x, const float* wmod, const float* style, const float* gy, const float* gx_acc,
-                          float* gx, float* gwmod, int batch, int cin, int h, int w, void* stream) {
+                          float* gx, float* gwmod, int batch, int cin, int h, int w, void* stream, bool actb, const float* noise,
+                          float* sums3, float slope, float gain) {
     W2E_REQUIRE(x && wmod && gy && gx && gwmod, "torgb_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && cin > 0 && h > 0 && w > 0, "torgb_bwd: bad dims");
     W2E_REQUIRE(batch < 65536, "torgb_bwd: batch too large");
@@ -268,18 +304,32 @@ static int torgb_bwd_impl(const float* x, const float* wmod, const float* style,
     int64_t per_split = ceil_div(hw, splits);
     per_split = (per_split + 255) & ~int64_t(255);
     splits = (int)ceil_div(hw, per_split);
-    if (splits > 1 && zero_async(gwmod, sizeof(float) * (style ? 1 : 3) * (size_t)batch * cin, s) != hipSuccess) {
+    if (splits > 1 && (zero_async(gwmod, sizeof(float) * (style ? 1 : 3) * (size_t)batch * cin, s) != hipSuccess ||
+                       (actb && zero_async(sums3, sizeof(float) * 3 * (size_t)batch * cin, s) != hipSuccess))) {
         set_error("torgb_bwd: memset failed");
         return 2;
     }
     dim3 grid((unsigned)(ceil_div(cin, 4) * splits), (unsigned)batch);
+#define W2E_TORGB_BWD(V, ACC, ACTB) \
+    torgb_bwd_kernel<V, ACC, ACTB><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split, noise, sums3, slope, gain)
     if ((hw & 3) == 0) {
-        if (gx_acc) torgb_bwd_kernel<4, true><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
-        else torgb_bwd_kernel<4, false><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        if (actb) {
+            if (gx_acc) W2E_TORGB_BWD(4, true, true);
+            else W2E_TORGB_BWD(4, false, true);
+        } else {
+            if (gx_acc) W2E_TORGB_BWD(4, true, false);
+            else W2E_TORGB_BWD(4, false, false);
+        }
     } else {
-        if (gx_acc) torgb_bwd_kernel<1, true><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
-        else torgb_bwd_kernel<1, false><<<grid, 256, 0, s>>>(x, wmod, style, gy, gx_acc, gx, gwmod, cin, hw, splits, per_split);
+        if (actb) {
+            if (gx_acc) W2E_TORGB_BWD(1, true, true);
+            else W2E_TORGB_BWD(1, false, true);
+        } else {
+            if (gx_acc) W2E_TORGB_BWD(1, true, false);
+            else W2E_TORGB_BWD(1, false, false);
+        }
     }
+#undef W2E_TORGB_BWD
     W2E_LAUNCH_CHECK("torgb_bwd");
     return 0;
 }

@@ -243,6 +243,20 @@ def unplanar(t, in_w):
     return t.permute(0, 1, 4, 2, 5, 3).reshape(b, n, 2 * hp, 2 * wpp)[:, :, :2 * hp - 1, :2 * w + 1].contiguous()
 
 
+# A ToRGB backward that already applied the producing StyledConv's activation backward (w2e_torgb_bwd_actbwd) leaves the
+# pre-activation gradient it returned, and the three sums that go with it, here for that layer's backward -- matched by tensor
+# IDENTITY (the engine hands the very tensor on; x has the ToRGB as its only consumer in the pass-through form, so nothing is
+# added to it on the way).  At most one entry is outstanding: the producing layer's backward is the next node to run.
+_PREACT_PENDING = {}
+
+
+def _take_preact(gout):
+    ent = _PREACT_PENDING.pop(id(gout), None)
+    if ent is not None and ent[0] is gout:
+        return ent[1]
+    return None
+
+
 class _StyledConv(torch.autograd.Function):
     """Fused StyledConv: out = lrelu(d * conv(Wp, s*x) [blur] + nw*noise + bias) * sqrt2 with
     d = rsqrt(s^2 @ wsq^T + eps) (model.py:234-276, 285-290, op/fused_act.py); with fuse_act=False just
@@ -278,6 +292,7 @@ class _StyledConv(torch.autograd.Function):
         x, s, d, wsq, noise, noise_w, bias, out, wp_b, blur_kernel = ctx.saved_tensors
         upsample, fuse_act = ctx.cfg
         n_skip, full = ctx.n_skip, x.shape[0]
+        gout_full = gout
         gout = _c(gout)
         if n_skip:  # rows [:n_skip] carry no gradient: batch-major tensors, so the tails are contiguous views
             x, s, out, gout = x[n_skip:], s[n_skip:], out[n_skip:], gout[n_skip:]
@@ -291,7 +306,10 @@ class _StyledConv(torch.autograd.Function):
         gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device)
         g_bias = g_nw = sums = dz = None
         blurred = False
-        if fuse_act:
+        pre_sums = _take_preact(gout_full) if fuse_act else None
+        if pre_sums is not None:  # gout already IS the pre-activation gradient (the ToRGB backward applied the activation backward)
+            gpre, sums = gout, pre_sums
+        elif fuse_act:
             sums = torch.empty((b, cout, 3), device=x.device, dtype=torch.float32)
             if (upsample and ow >= 256 and ow % 4 == 0 and tuple(blur_kernel.shape) == (4, 4) and not _lib.get_option("deterministic")
                     and _lib.get_option("tune_fuse") != 0):  # (tune_fuse = 0: the two-kernel form, for comparison)
@@ -308,14 +326,15 @@ class _StyledConv(torch.autograd.Function):
                 gpre = torch.empty_like(out)
                 call("w2e_bias_act_bwd_reduce", ptr(gout), ptr(out), ptr(noise), ptr(gpre), ptr(sums), b, cout, oh * ow,
                      0.2, SQRT2, stream_ptr())
-            if bias is not None and ctx.needs_input_grad[5]:
-                g_bias = sums[..., 2].sum(0)
-            if noise is not None and ctx.needs_input_grad[4]:
-                g_nw = sums[..., 1].sum().reshape(1)
         else:
             gpre = gout
             if d is not None:
                 dz = (gout * out).sum((2, 3))
+        if fuse_act:
+            if bias is not None and ctx.needs_input_grad[5]:
+                g_bias = sums[..., 2].sum(0)
+            if noise is not None and ctx.needs_input_grad[4]:
+                g_nw = sums[..., 1].sum().reshape(1)
         if upsample and not blurred:
             # adjoint of Blur(pad=(1,1)) back onto the (2h+1)x(2w+1) transposed-conv grid, then the
             # stride-2 conv that is the adjoint of conv_transpose2d
@@ -409,7 +428,10 @@ class _ToRGB(torch.autograd.Function):
     ToRGB input gradient by the kernel (w2e_torgb_bwd_acc) -- instead of autograd adding two activation-sized tensors."""
 
     @staticmethod
-    def forward(ctx, x, wmod, style, bias, skip, upk, passthrough=False):
+    def forward(ctx, x, wmod, style, bias, skip, upk, passthrough=False, producer_act=None):
+        """`producer_act` = (noise [1,1,h,w] | None,): x is the output of a fused StyledConv (slope 0.2, gain sqrt 2) consumed by this
+        node alone (the pass-through form, or the last layer): the backward then returns that layer's PRE-activation gradient
+        (see _PREACT_PENDING)."""
         x_in = x
         x, wmod = _c(x), _c(wmod)
         b, cin, h, w = x.shape
@@ -425,7 +447,8 @@ class _ToRGB(torch.autograd.Function):
                 raise RuntimeError(f"to_rgb: the shared weight must be [3,{cin}], got {tuple(wmod.shape)}")
             call("w2e_torgb_styled_fwd", ptr(x), ptr(wmod), ptr(style), ptr(bias_c), ptr(skip_c),
                  ptr(upk) if skip is not None else None, ptr(y), b, cin, h, w, stream_ptr())
-        ctx.save_for_backward(x, wmod, style, upk if skip is not None else None)
+        ctx.save_for_backward(x, wmod, style, upk if skip is not None else None, producer_act[0] if producer_act is not None else None)
+        ctx.actb = producer_act is not None  # (the caller vouches that this node is x's only consumer)
         ctx.has = (bias is not None, skip is not None, tuple(bias.shape) if bias is not None else None)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
         if passthrough:
@@ -435,12 +458,12 @@ class _ToRGB(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, gx_next=None):
-        x, wmod, style, upk = ctx.saved_tensors
+        x, wmod, style, upk, act_noise = ctx.saved_tensors
         has_bias, has_skip, bias_shape = ctx.has
         n_skip = ctx.n_skip
         b, cin, h, w = x.shape
         if gy is None:  # only the pass-through output was used
-            return gx_next, None, None, None, None, None, None
+            return gx_next, None, None, None, None, None, None, None
         gy = _c(gy)
         gx = torch.empty_like(x)
         acc = _c(gx_next) if gx_next is not None else None
@@ -449,29 +472,35 @@ class _ToRGB(torch.autograd.Function):
             accs = acc[n_skip:] if acc is not None else None
         else:
             xs, gys, gxs, accs = x, gy, gx, acc
-        if style is None:
-            gw_full, gw = _zeros_with_tail(b, n_skip, (3, cin), x.device)
-            call("w2e_torgb_bwd_acc", ptr(xs), ptr(wmod[n_skip:] if n_skip else wmod), ptr(gys), ptr(accs), ptr(gxs), ptr(gw),
-                 b - n_skip, cin, h, w, stream_ptr())
-            g_wmod, g_style = gw_full.view_as(wmod), None
+        ws = wmod if style is not None else (wmod[n_skip:] if n_skip else wmod)
+        sts = None if style is None else (style[n_skip:] if n_skip else style)
+        gw_full, gw = _zeros_with_tail(b, n_skip, (cin,) if style is not None else (3, cin), x.device)
+        if ctx.actb:
+            # x is the activated output of the StyledConv below: hand that layer its pre-activation gradient and sums directly
+            sums3 = torch.empty((b - n_skip, cin, 3), device=x.device, dtype=torch.float32)
+            call("w2e_torgb_bwd_actbwd", ptr(xs), ptr(ws), ptr(sts), ptr(gys), ptr(accs), ptr(act_noise), ptr(gxs), ptr(gw), ptr(sums3),
+                 b - n_skip, cin, h, w, 0.2, SQRT2, stream_ptr())
+            _PREACT_PENDING.clear()
+            _PREACT_PENDING[id(gx)] = (gx, sums3)
+        elif style is None:
+            call("w2e_torgb_bwd_acc", ptr(xs), ptr(ws), ptr(gys), ptr(accs), ptr(gxs), ptr(gw), b - n_skip, cin, h, w, stream_ptr())
         else:
-            gst_full, gst = _zeros_with_tail(b, n_skip, (cin,), x.device)
-            call("w2e_torgb_styled_bwd", ptr(xs), ptr(wmod), ptr(style[n_skip:] if n_skip else style), ptr(gys), ptr(accs),
-                 ptr(gxs), ptr(gst), b - n_skip, cin, h, w, stream_ptr())
-            g_wmod, g_style = None, gst_full
+            call("w2e_torgb_styled_bwd", ptr(xs), ptr(ws), ptr(sts), ptr(gys), ptr(accs), ptr(gxs), ptr(gw), b - n_skip, cin, h, w,
+                 stream_ptr())
+        g_wmod, g_style = (gw_full.view_as(wmod), None) if style is None else (None, gw_full)
         gb = gys.sum((0, 2, 3)).reshape(bias_shape) if (has_bias and ctx.needs_input_grad[3]) else None
         gskip = None
         if has_skip:  # adjoint of Upsample(up=2, pad=(2,1)): down=2, un-flipped taps, leading pad 4-1-2
             gskip = torch.empty((b, 3, h // 2, w // 2), device=x.device, dtype=torch.float32)  # rows [:n_skip]: see _StyledConv
             _upfirdn2d_raw(gys, upk, h // 2, w // 2, 1, 2, 1, 1, False, out=gskip[n_skip:] if n_skip else gskip)
-        return gx, g_wmod, g_style, gb, gskip, None, None
+        return gx, g_wmod, g_style, gb, gskip, None, None, None
 
 
-def to_rgb(x, wmod, bias, skip, upk, passthrough=False, style=None):
+def to_rgb(x, wmod, bias, skip, upk, passthrough=False, style=None, producer_act=None):
     """y = sum_i wmod[b,c,i] x[b,i] + bias + Upsample(skip)   (model.py:353-362); with `passthrough` -> (y, x).
     With `style` [B,cin]: wmod is the shared [3,cin] scale*W (treated as frozen) and the weight of sample b is
     wmod[c,i]*style[b,i]."""
-    return _ToRGB.apply(x, wmod, style, bias, skip, upk, passthrough)
+    return _ToRGB.apply(x, wmod, style, bias, skip, upk, passthrough, producer_act)
 
 
 # ------------------------------------------------------------------------------------------ K5

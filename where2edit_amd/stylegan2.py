@@ -310,6 +310,7 @@ class StyledConv(nn.Module):
         fusable = (conv.kernel_size == 3 and not conv.downsample and noise is not None and noise.ndim == 4
                    and noise.shape[0] == 1 and noise.shape[1] == 1
                    and not (conv.upsample and tuple(conv.blur.kernel.shape) != (4, 4)))
+        self._act_noise = None  # (set below when the fused epilogue produced the output: what a following ToRGB may fold, see _synthesis)
         if not fusable:
             # per-sample / random noise (randomize_noise=True) or a 1x1 StyledConv: unfused composition of the same ops
             out, style = conv(input, style, input_is_stylespace=input_is_stylespace)
@@ -319,8 +320,10 @@ class StyledConv(nn.Module):
         style = conv._style(style, batch, input_is_stylespace)
         s2d = style.reshape(batch, conv.in_channel)
         fwd, bwd, wsq = conv._derived()
-        out = K.styled_conv(input, s2d, wsq if conv.demodulate else None, noise.contiguous(), self.noise.weight, self.activate.bias, (fwd, bwd),
+        noise_c = noise.contiguous()
+        out = K.styled_conv(input, s2d, wsq if conv.demodulate else None, noise_c, self.noise.weight, self.activate.bias, (fwd, bwd),
                             conv.blur.kernel if conv.upsample else None, conv.upsample)
+        self._act_noise = (noise_c,)
         return out, style
 
 
@@ -337,8 +340,10 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None, input_is_stylespace=False, passthrough=False):
-        """`passthrough` (synthesis loop, training): returns (rgb, style, input) -- see functional._ToRGB."""
+    def forward(self, input, style, skip=None, input_is_stylespace=False, passthrough=False, producer_act=None):
+        """`passthrough` (synthesis loop, training): returns (rgb, style, input) -- see functional._ToRGB.  `producer_act`: the
+        `_act_noise` of the fused StyledConv whose output `input` is (pass-through form only): the ToRGB backward then applies
+        that layer's activation backward to the gradient it returns (w2e_torgb_bwd_actbwd)."""
         conv = self.conv
         batch = input.shape[0]
         style = conv._style(style, batch, input_is_stylespace)
@@ -358,10 +363,10 @@ class ToRGB(nn.Module):
         passed = None
         if passthrough:
             out, passed = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None,
-                                   True, style=st)
+                                   True, style=st, producer_act=producer_act if os.environ.get("W2E_TUNE_NO_RGBACT") is None else None)
         else:
             out = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None,
-                           style=st)
+                           style=st, producer_act=producer_act if os.environ.get("W2E_TUNE_NO_RGBACT") is None else None)
         if skip is not None and not fuse_skip:
             out = out + self.upsample(skip)
         if passthrough:
@@ -509,19 +514,25 @@ class Generator(nn.Module):
             batch = latent.shape[0]
             latent = [s.view(batch, 1, s.shape[1], 1, 1) for s in batched]
             input_is_stylespace = True
+        producer = None  # the fused-epilogue record of the StyledConv whose output `out` currently is
         for n, (mod, is_rgb, widx, nidx) in enumerate(plan):
             sty = latent[n] if input_is_stylespace else latent[:, widx]
             if is_rgb:
                 # the activation feeds this ToRGB and the next conv: route it THROUGH the ToRGB node when gradients flow
-                # (one consumer, the two gradients are joined inside torgb_bwd instead of by an elementwise add)
+                # (one consumer, the two gradients are joined inside torgb_bwd instead of by an elementwise add -- and the
+                # producing StyledConv's activation backward is applied there too)
                 if on_layer is None and n + 1 < len(plan) and torch.is_grad_enabled() and out.requires_grad and not _NO_RGBPASS:
-                    skip, s, out = mod(out, sty, skip, input_is_stylespace=input_is_stylespace, passthrough=True)
+                    skip, s, out = mod(out, sty, skip, input_is_stylespace=input_is_stylespace, passthrough=True, producer_act=producer)
+                elif on_layer is None and n + 1 == len(plan) and torch.is_grad_enabled() and out.requires_grad and not _NO_RGBPASS:
+                    skip, s = mod(out, sty, skip, input_is_stylespace=input_is_stylespace, producer_act=producer)  # (the last layer: sole consumer too)
                 else:
                     skip, s = mod(out, sty, skip, input_is_stylespace=input_is_stylespace)
                 if on_layer is not None:
                     skip = on_layer(n, True, skip)
+                producer = None
             else:
                 out, s = mod(out, sty, noise=noise[nidx], input_is_stylespace=input_is_stylespace)
+                producer = getattr(mod, "_act_noise", None)
                 if on_layer is not None:
                     out = on_layer(n, False, out)
             style_vector.append(s)
