@@ -29,7 +29,15 @@ class Generator(_BaseGenerator):
             recorded.append(act)
             return act
 
-        image, style_vector = self._synthesis(latent, noise, input_is_stylespace, on_layer)
+        hooks = None
+        if not return_features:  # nothing to record: only the blended layer and the ToRGB after it need the hook; every other
+            hooks = set()        # layer keeps the fused training forms of the plain generator
+            if attention_map is not None and attention_layer > 0:
+                plan = self._layers()
+                n0 = attention_layer - 1
+                hooks.add(n0)
+                hooks.update([n for n in range(n0 + 1, len(plan)) if plan[n][1]][:1])
+        image, style_vector = self._synthesis(latent, noise, input_is_stylespace, on_layer, hooks)
         if return_latents:
             return image, latent, style_vector
         if return_features:

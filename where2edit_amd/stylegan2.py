@@ -503,7 +503,10 @@ class Generator(nn.Module):
             return latent, [s.view(batch, 1, s.shape[1], 1, 1) for s in batched]
         return latent, [mod.conv._style(latent[:, widx], batch, False) for mod, _, widx, _ in plan]
 
-    def _synthesis(self, latent, noise, input_is_stylespace, on_layer=None):
+    def _synthesis(self, latent, noise, input_is_stylespace, on_layer=None, hook_layers=None):
+        """`on_layer(n, is_rgb, act) -> act` is called after layer n of the plan (every layer, or only those in `hook_layers`);
+        layers without a hook take the fused training forms (ToRGB pass-through, activation backward inside the ToRGB backward)."""
+        hook_all = on_layer
         batch_ref = latent[0] if input_is_stylespace else latent
         out = self.input(batch_ref)
         skip = None
@@ -517,6 +520,7 @@ class Generator(nn.Module):
         producer = None  # the fused-epilogue record of the StyledConv whose output `out` currently is
         for n, (mod, is_rgb, widx, nidx) in enumerate(plan):
             sty = latent[n] if input_is_stylespace else latent[:, widx]
+            on_layer = hook_all if (hook_layers is None or n in hook_layers) else None
             if is_rgb:
                 # the activation feeds this ToRGB and the next conv: route it THROUGH the ToRGB node when gradients flow
                 # (one consumer, the two gradients are joined inside torgb_bwd instead of by an elementwise add -- and the
@@ -535,6 +539,7 @@ class Generator(nn.Module):
                 producer = getattr(mod, "_act_noise", None)
                 if on_layer is not None:
                     out = on_layer(n, False, out)
+                    producer = None  # (the hook may have replaced the activation)
             style_vector.append(s)
         return skip, style_vector
 
