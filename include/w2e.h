@@ -117,15 +117,6 @@ int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, float scale
 int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
                    float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
                    const float* noise_w, const float* bias, const float* dot_with, float* dot_out, void* stream);
-/* The fused SAME StyledConv (mode 0, act = 1) together with the ToRGB that consumes it (model.py:334-340 + :353-362), for layers with
- * n_ch <= 64 (the 512^2 and 1024^2 layers of the FFHQ-1024 generator; one wave row of the tile holds all N channels of its pixels):
- * y as w2e_modconv3x3, and rgb_out [B,3,h,w] = sum_o rgb_w[c,o]*rgb_style[b,o]*y[b,o] + rgb_bias[c] + Upsample(rgb_skip) as
- * w2e_torgb_styled_fwd would compute it from y (rgb_style NULL: rgb_w is the per-sample [B,3,N] weight).  rgb_bias [3] and
- * rgb_skip [B,3,h/2,w/2] (with its 4x4 kernel rgb_upk) may be NULL.  fp32 conv precision only. */
-int w2e_modconv3x3_rgb(const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y, int batch, int k_ch,
-                       int n_ch, int h, int w, const float* noise, const float* noise_w, const float* bias, const float* rgb_w,
-                       const float* rgb_style, const float* rgb_bias, const float* rgb_skip, const float* rgb_upk, float* rgb_out,
-                       void* stream);
 
 /* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
  *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */

@@ -660,38 +660,6 @@ def test_upfirdn_stream_dense_adjoint_equals_tile_kernel(h, w, separable, w2e_op
         assert_close(y, ref, 2e-6, f"stream dense {oh}x{ow}")
 
 
-@pytest.mark.parametrize("b,k,n,h,w,with_skip,styled", [(2, 64, 64, 64, 64, True, True), (3, 32, 32, 96, 128, True, True), (1, 40, 24, 70, 36, False, True),
-                                                         (2, 128, 64, 32, 32, True, False), (2, 64, 32, 128, 128, False, False)])
-def test_modconv_with_torgb_epilogue(b, k, n, h, w, with_skip, styled):
-    """w2e_modconv3x3_rgb: the fused SAME StyledConv and, from its epilogue, the ToRGB that consumes it -- the activation equal
-    to w2e_modconv3x3's (same tile, same arithmetic: bit for bit when the library would pick that tile anyway, 1e-6 otherwise) and
-    the RGB image equal to the ToRGB kernel run on that activation; ragged channel counts, non-square and odd tile counts."""
-    from where2edit_amd import functional as K
-    from where2edit_amd._lib import call, ptr, stream_ptr
-    g = torch.Generator().manual_seed(17 * k + n + h)
-    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
-    pack = K.conv_pack(wt, (k * 9) ** -0.5, False, False)
-    x = torch.randn(b, k, h, w, generator=g).to(DEV)
-    s_in, s_out = (torch.randn(b, k, generator=g).to(DEV) * 0.3 + 1), (torch.rand(b, n, generator=g).to(DEV) + 0.5)
-    noise, nw, bias = torch.randn(1, 1, h, w, generator=g).to(DEV), torch.randn(1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
-    rgb_bias = torch.randn(3, generator=g).to(DEV)
-    skip = torch.randn(b, 3, h // 2, w // 2, generator=g).to(DEV) if with_skip else None
-    upk = cu(seeded.fir_kernel(gain=4.0))
-    st = torch.randn(b, n, generator=g).to(DEV) if styled else None
-    rw = (torch.randn(3, n, generator=g) * 0.2).to(DEV) if styled else (torch.randn(b, 3, n, generator=g) * 0.2).to(DEV)
-    y_ref, _ = K._modconv_raw(K.MODE_SAME, x, pack, s_in, s_out, h, w, act=(noise, nw, bias))
-    rgb_ref = torch.empty(b, 3, h, w, device=DEV)
-    if styled:
-        call("w2e_torgb_styled_fwd", ptr(y_ref), ptr(rw), ptr(st), ptr(rgb_bias), ptr(skip), ptr(upk) if with_skip else None, ptr(rgb_ref), b, n, h, w, stream_ptr())
-    else:
-        call("w2e_torgb_fwd", ptr(y_ref), ptr(rw), ptr(rgb_bias), ptr(skip), ptr(upk) if with_skip else None, ptr(rgb_ref), b, n, h, w, stream_ptr())
-    y, rgb = torch.full((b, n, h, w), float("nan"), device=DEV), torch.full((b, 3, h, w), float("nan"), device=DEV)
-    call("w2e_modconv3x3_rgb", ptr(x), ptr(pack), ptr(s_in), ptr(s_out), ptr(y), b, k, n, h, w, ptr(noise), ptr(nw), ptr(bias), ptr(rw), ptr(st),
-         ptr(rgb_bias), ptr(skip), ptr(upk) if with_skip else None, ptr(rgb), stream_ptr())
-    assert_close(y, y_ref, 3e-6, "activation")  # (the reference call may split K and join with atomics)
-    assert_close(rgb, rgb_ref, 5e-6, "rgb")
-
-
 @pytest.mark.parametrize("cin,h,styled,with_acc,with_noise", [(32, 64, True, True, True), (12, 18, False, False, True), (512, 8, True, True, False),
                                                                (64, 128, False, True, True)])
 def test_torgb_backward_with_fused_activation_backward(cin, h, styled, with_acc, with_noise):

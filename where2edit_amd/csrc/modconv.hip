@@ -60,20 +60,9 @@ struct ConvParams {
     int in_off;          // DOWN: the input origin is shifted by in_off (-1 = a stride-2 convolution with padding 1 of an in_h x in_w image)
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
     unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
-    // EPI_ACT_RGB: rgb_w [3,N] (shared scale*W) with rgb_style [B,N], or rgb_w [B,3,N] with rgb_style NULL; rgb_bias [3] | NULL;
-    // rgb_skip [B,3,H/2,W/2] | NULL with its 4x4 up-sampling kernel rgb_upk [16]; rgb_out [B,3,H,W]
-    const float* rgb_w;
-    const float* rgb_style;
-    const float* rgb_bias;
-    const float* rgb_skip;
-    const float* rgb_upk;
-    float* rgb_out;
 };
 
-// EPI_ACT_RGB = EPI_ACT + the ToRGB that follows the layer (model.py:353-362), for tiles whose ONE wave row holds all N output
-// channels of its pixels (WO = 1, N <= 32*NOB): rgb[c,p] = sum_o rgb_w[c,o] * rgb_style[b,o] * y[o,p] + bias[c] + up2(skip)[c,p] is
-// accumulated from the activated values while they are stored, so the separate pass over the activation is not needed.
-enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3, EPI_ACT_RGB = 4 };
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3 };
 
 // Internal variant of W2E_CONV_UP chosen by the host per layer: a workgroup computes ALL FOUR output phases of a
 // (4x smaller) input-pixel tile from one staged patch and all 9 taps -- the NPB accumulator columns of a wave are
@@ -713,10 +702,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     }
 
     // ---- epilogue
-    constexpr bool ACT = EPI == EPI_ACT || EPI == EPI_ACT_RGB;
-    constexpr bool RGB = EPI == EPI_ACT_RGB;
-    static_assert(!RGB || (WO == 1 && MODE == W2E_CONV_SAME), "the ToRGB epilogue needs all N channels of a pixel in one wave row");
-    const float nw = (ACT && p.noise) ? p.noise_w[0] : 0.f;
+    const float nw = (EPI == EPI_ACT && p.noise) ? p.noise_w[0] : 0.f;
     float* red = smem;  // EPI_DOT: TN partial sums (reuses the weight tile after a barrier)
     if (EPI == EPI_DOT) {
         __syncthreads();
@@ -744,7 +730,7 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         const int ph_pb = (MODE == CONV_UPALL) ? pb / NPX : phase;
         if (is_up(MODE)) pix[pb] = (ph_pb * (p.H + 1) + gy[pb]) * ((p.W + 4) & ~3) + gx[pb];
         else pix[pb] = gy[pb] * p.out_w + gx[pb];
-        nz[pb] = (ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
+        nz[pb] = (EPI == EPI_ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
     }
     const int out_plane = is_up(MODE) ? 4 * (p.H + 1) * ((p.W + 4) & ~3) : p.out_h * p.out_w;
     // Output (and dot_with) accesses as buffer operations on a descriptor spanning this image's N planes: per-lane byte
@@ -760,66 +746,14 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     unsigned yoff[NPB];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) yoff[pb] = valid[pb] ? (unsigned)pix[pb] * 4u + (unsigned)(4 * half) * plane_bytes : 0xfffffff0u;
-    // ---- EPI_ACT_RGB: per-sample ToRGB weights of the tile's channels into LDS (free now), in the accumulator-row order of a lane
-    // half: entry [half][ob][r] = the 3 weights of channel n0 + ob*32 + (r&3) + 8*(r>>2) + 4*half; the up-sampled skip (+ bias)
-    // of the lane's pixels is fetched before the first store (see the vmcnt note above)
-    float rgb[3][NPB], urgb[3][NPB];
-    float3* const rgbw = reinterpret_cast<float3*>(smem);
-    int rgb_row = 0;
-    if (RGB) {
-        __syncthreads();  // every wave is done with the operand images
-        for (int e = tid; e < 2 * NOB * 16; e += NT) {
-            const int hh = e / (NOB * 16), ob2 = (e / 16) % NOB, r = e % 16;
-            const int o = n0 + ob2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float3 wv = make_float3(0.f, 0.f, 0.f);
-            if (o < p.N) {
-                if (p.rgb_style) {
-                    const float st = p.rgb_style[(int64_t)b * p.N + o];
-                    wv = make_float3(p.rgb_w[o] * st, p.rgb_w[p.N + o] * st, p.rgb_w[2 * p.N + o] * st);
-                } else {
-                    const float* wb = p.rgb_w + (int64_t)b * 3 * p.N;
-                    wv = make_float3(wb[o], wb[p.N + o], wb[2 * p.N + o]);
-                }
-            }
-            rgbw[e] = wv;
-        }
-        const int Hs = p.H >> 1, Ws = p.W >> 1;
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                rgb[c][pb] = 0.f;
-                float u = p.rgb_bias ? p.rgb_bias[c] : 0.f;
-                if (p.rgb_skip && valid[pb]) {
-                    // Upsample: zero-stuff x2, pad (2,1), 4x4 kernel applied flipped (model.py:31-49, op/upfirdn2d.py:47): only the
-                    // taps with (y+ky-2) and (x+kx-2) even hit a sample -- 2x2 of the 16 (as w2e_torgb_fwd)
-                    const float* sp = p.rgb_skip + ((int64_t)b * 3 + c) * Hs * Ws;
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const int ky = (gy[pb] & 1) + 2 * a, sy = (gy[pb] + ky - 2) >> 1;
-                        if (gy[pb] + ky - 2 < 0 || sy >= Hs) continue;
-#pragma unroll
-                        for (int d = 0; d < 2; ++d) {
-                            const int kx = (gx[pb] & 1) + 2 * d, sx = (gx[pb] + kx - 2) >> 1;
-                            if (gx[pb] + kx - 2 < 0 || sx >= Ws) continue;
-                            u += p.rgb_upk[15 - (ky * 4 + kx)] * sp[sy * Ws + sx];
-                        }
-                    }
-                }
-                urgb[c][pb] = u;
-            }
-        }
-        __syncthreads();  // the weights are in LDS
-    }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
-        if (RGB) rgb_row = (half * NOB + ob) * 16;
         float os[16], bs[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             os[r] = (o < p.N && p.out_scale) ? p.out_scale[b * p.N + o] : 1.f;
-            bs[r] = ((ACT || EPI == EPI_PRELU) && o < p.N && p.bias) ? p.bias[o] : 0.f;
+            bs[r] = ((EPI == EPI_ACT || EPI == EPI_PRELU) && o < p.N && p.bias) ? p.bias[o] : 0.f;
         }
         float sl[EPI == EPI_PRELU ? 16 : 1];
         if (EPI == EPI_PRELU) {
@@ -872,13 +806,9 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb) {
                     float v = acc[ob][pb][r] * os[r];
-                    if (ACT) {
+                    if (EPI == EPI_ACT) {
                         v += bs[r] + nz[pb];
                         v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
-                    }
-                    if (RGB) {
-                        const float3 wm = rgbw[rgb_row + r];  // (LDS; rows of channels >= N hold zeros)
-                        rgb[0][pb] += wm.x * v, rgb[1][pb] += wm.y * v, rgb[2][pb] += wm.z * v;
                     }
                     if (EPI == EPI_PRELU) {
                         v += bs[r];
@@ -887,16 +817,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
                     if (W2E_SKIP(p, 1) && v != 123456.789f) continue;  // tuning aid: no stores, arithmetic kept alive
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[pb], soff, 0);
                 }
-            }
-        }
-    }
-    if (RGB) {  // the two lane halves hold complementary channel rows of the same pixels
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float t = rgb[c][pb] + __shfl_xor(rgb[c][pb], 32, 64);
-                if (half == 0 && valid[pb]) p.rgb_out[(((int64_t)b * 3 + c) * p.H + gy[pb]) * p.W + gx[pb]] = t + urgb[c][pb];
             }
         }
     }
@@ -1069,19 +989,10 @@ extern "C" int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, 
 // The engine behind w2e_modconv3x3 (StyleGAN2 layers) and w2e_conv3x3 (plain convolutions with folded BatchNorm / PReLU:
 // IR-SE50, the e4e encoder).  prelu: epilogue v = prelu(out_scale*acc + bias[o], slope[o]) (SAME / DOWN, no split-K);
 // down_pad: DOWN reads an (2h) x (2w) image with a one-pixel zero border on the top/left (stride 2, padding 1).
-struct RgbArgs {  // the ToRGB folded into the epilogue (EPI_ACT_RGB)
-    const float* w;
-    const float* style;
-    const float* bias;
-    const float* skip;
-    const float* upk;
-    float* out;
-};
-
 static int conv_impl(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y,
                      int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise, const float* noise_w,
                      const float* bias, const float* dot_with, float* dot_out, const float* slope, int prelu, int down_pad,
-                     void* stream, const RgbArgs* rgb = nullptr) {
+                     void* stream) {
     W2E_REQUIRE(mode >= 0 && mode <= 2, "modconv3x3: bad mode %d", mode);
     W2E_REQUIRE(x && wp && y, "modconv3x3: null tensor");
     W2E_REQUIRE(batch >= 0 && k_ch > 0 && n_ch > 0 && h > 0 && w > 0, "modconv3x3: bad dims");
@@ -1103,7 +1014,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     ConvParams p{};
     p.x = x, p.wp = wp, p.in_scale = in_scale, p.out_scale = out_scale, p.y = y;
     p.noise = noise, p.noise_w = noise_w, p.bias = bias, p.dot_with = dot_with, p.dot_out = dot_out;
-    if (rgb) p.rgb_w = rgb->w, p.rgb_style = rgb->style, p.rgb_bias = rgb->bias, p.rgb_skip = rgb->skip, p.rgb_upk = rgb->upk, p.rgb_out = rgb->out;
     p.batch = batch, p.K = k_ch, p.N = n_ch, p.H = h, p.W = w;
     if (mode == W2E_CONV_SAME) p.in_h = h, p.in_w = w, p.out_h = h, p.out_w = w;
     else if (mode == W2E_CONV_UP) p.in_h = h, p.in_w = w, p.out_h = 2 * h + 1, p.out_w = 2 * w + 1;
@@ -1218,12 +1128,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
         const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
         if (fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
-    if (rgb) {  // the tiles whose single wave row spans all N channels: 32x512 (N <= 32) and 64x1024 (N <= 64), unsplit
-        W2E_REQUIRE(mode == W2E_CONV_SAME && act && !dot_with && !prelu && n_ch <= 64 && rgb->w && rgb->out && (!rgb->skip || rgb->upk) &&
-                        (!rgb->skip || ((h & 1) == 0 && (w & 1) == 0)),
-                    "modconv3x3_rgb: the ToRGB epilogue is for the fused SAME layer with N <= 64 (N = %d)", n_ch);
-        best = n_ch <= 32 ? 8 : 1, best_splits = 1;
-    }
     if (opt.deterministic || prelu) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
@@ -1323,12 +1227,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
         return 2;
     }
     bool ok = false;
-    if (rgb) {
-        W2E_REQUIRE(!use_x3 && p.splits == 1 && (use_dma == (best == 1)), "modconv3x3_rgb: unexpected pipeline for the ToRGB epilogue");
-        if (best == 8) launch_cfg<W2E_CONV_SAME, EPI_ACT_RGB, 1, 4, 1, 4, 8>(p, (int)grid, lds, s);
-        else launch_cfg<W2E_CONV_SAME, EPI_ACT_RGB, 2, 4, 1, 8, 8, 1>(p, (int)grid, lds, s);
-        ok = true;
-    } else if (use_x3 && use_all) {
+    if (use_x3 && use_all) {
         ok = launch_x3_up(best, p, (int)grid, lds, s);
     } else if (use_x3 && mode == W2E_CONV_DOWN) {
         if (dot_with) ok = launch_x3_down<EPI_DOT>(best, p, (int)grid, lds, s);
@@ -1403,16 +1302,6 @@ extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const f
                               void* stream) {
     return conv_impl(mode, x, wp, in_scale, out_scale, y, batch, k_ch, n_ch, h, w, act, noise, noise_w, bias, dot_with, dot_out,
                      nullptr, 0, 0, stream);
-}
-
-extern "C" int w2e_modconv3x3_rgb(const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y, int batch,
-                                  int k_ch, int n_ch, int h, int w, const float* noise, const float* noise_w, const float* bias,
-                                  const float* rgb_w, const float* rgb_style, const float* rgb_bias, const float* rgb_skip,
-                                  const float* rgb_upk, float* rgb_out, void* stream) {
-    W2E_REQUIRE(options().conv_precision == 0, "modconv3x3_rgb: fp32 conv precision only");
-    const RgbArgs rgb{rgb_w, rgb_style, rgb_bias, rgb_skip, rgb_upk, rgb_out};
-    return conv_impl(W2E_CONV_SAME, x, wp, in_scale, out_scale, y, batch, k_ch, n_ch, h, w, 1, noise, noise_w, bias, nullptr, nullptr,
-                     nullptr, 0, 0, stream, &rgb);
 }
 
 extern "C" int w2e_conv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y,
