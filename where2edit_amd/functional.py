@@ -243,18 +243,22 @@ def unplanar(t, in_w):
     return t.permute(0, 1, 4, 2, 5, 3).reshape(b, n, 2 * hp, 2 * wpp)[:, :, :2 * hp - 1, :2 * w + 1].contiguous()
 
 
-# A ToRGB backward that already applied the producing StyledConv's activation backward (w2e_torgb_bwd_actbwd) leaves the
-# pre-activation gradient it returned, and the three sums that go with it, here for that layer's backward -- matched by tensor
-# IDENTITY (the engine hands the very tensor on; x has the ToRGB as its only consumer in the pass-through form, so nothing is
-# added to it on the way).  At most one entry is outstanding: the producing layer's backward is the next node to run.
-_PREACT_PENDING = {}
+class ActLink:
+    """Pairs ONE fused StyledConv node with the ToRGB node that is the only consumer of its output (the pass-through form of the
+    synthesis loop, or the last layer).  The ToRGB backward, which has the activation and the gradient it returns in registers,
+    applies the StyledConv's activation backward itself (w2e_torgb_bwd_actbwd) and leaves the pre-activation gradient tensor and
+    its three per-(sample, channel) sums here; the StyledConv backward takes them if -- and only if -- the gradient it receives
+    is that very tensor (the engine hands it on untouched: nothing else contributes to it)."""
 
+    __slots__ = ("noise", "gpre", "sums")
 
-def _take_preact(gout):
-    ent = _PREACT_PENDING.pop(id(gout), None)
-    if ent is not None and ent[0] is gout:
-        return ent[1]
-    return None
+    def __init__(self, noise):
+        self.noise, self.gpre, self.sums = noise, None, None
+
+    def take(self, gout):
+        gpre, sums = self.gpre, self.sums
+        self.gpre = self.sums = None
+        return sums if (gpre is not None and gpre is gout) else None
 
 
 class _StyledConv(torch.autograd.Function):
@@ -265,7 +269,7 @@ class _StyledConv(torch.autograd.Function):
     never optimised on this path: coach.py:174-180 optimises net.mapper only)."""
 
     @staticmethod
-    def forward(ctx, x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act):
+    def forward(ctx, x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act, link=None):
         x, s = _c(x), _c(s)
         b, cin, h, w = x.shape
         wp_f, wp_b = packs
@@ -283,6 +287,7 @@ class _StyledConv(torch.autograd.Function):
             out, _ = _modconv_raw(MODE_SAME, x, wp_f, s, d, h, w, act=act)
         ctx.save_for_backward(x, s, d, wsq, noise, noise_w, bias, out, wp_b, blur_kernel)
         ctx.cfg = (upsample, fuse_act)
+        ctx.link = link  # (an ActLink shared with the consuming ToRGB node, or None)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
         return out
 
@@ -306,7 +311,7 @@ class _StyledConv(torch.autograd.Function):
         gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device)
         g_bias = g_nw = sums = dz = None
         blurred = False
-        pre_sums = _take_preact(gout_full) if fuse_act else None
+        pre_sums = ctx.link.take(gout_full) if (fuse_act and ctx.link is not None) else None
         if pre_sums is not None:  # gout already IS the pre-activation gradient (the ToRGB backward applied the activation backward)
             gpre, sums = gout, pre_sums
         elif fuse_act:
@@ -355,11 +360,11 @@ class _StyledConv(torch.autograd.Function):
                  ptr(bias) if fuse_act else None, ptr(d), ptr(s), ptr(wsq), ptr(gs), None, b, cin, cout, stream_ptr())
         if n_skip:
             gx = gx_full
-        return gx, gs_full, None, None, g_nw, g_bias, None, None, None, None
+        return gx, gs_full, None, None, g_nw, g_bias, None, None, None, None, None
 
 
-def styled_conv(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample):
-    return _StyledConv.apply(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, True)
+def styled_conv(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, link=None):
+    return _StyledConv.apply(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, True, link)
 
 
 def modconv(x, s, wsq, packs, blur_kernel, upsample):
@@ -429,9 +434,8 @@ class _ToRGB(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wmod, style, bias, skip, upk, passthrough=False, producer_act=None):
-        """`producer_act` = (noise [1,1,h,w] | None,): x is the output of a fused StyledConv (slope 0.2, gain sqrt 2) consumed by this
-        node alone (the pass-through form, or the last layer): the backward then returns that layer's PRE-activation gradient
-        (see _PREACT_PENDING)."""
+        """`producer_act` = the ActLink of the fused StyledConv (slope 0.2, gain sqrt 2) whose output x is, when this node is its only
+        consumer (the pass-through form, or the last layer): the backward then returns that layer's PRE-activation gradient."""
         x_in = x
         x, wmod = _c(x), _c(wmod)
         b, cin, h, w = x.shape
@@ -447,8 +451,8 @@ class _ToRGB(torch.autograd.Function):
                 raise RuntimeError(f"to_rgb: the shared weight must be [3,{cin}], got {tuple(wmod.shape)}")
             call("w2e_torgb_styled_fwd", ptr(x), ptr(wmod), ptr(style), ptr(bias_c), ptr(skip_c),
                  ptr(upk) if skip is not None else None, ptr(y), b, cin, h, w, stream_ptr())
-        ctx.save_for_backward(x, wmod, style, upk if skip is not None else None, producer_act[0] if producer_act is not None else None)
-        ctx.actb = producer_act is not None  # (the caller vouches that this node is x's only consumer)
+        ctx.save_for_backward(x, wmod, style, upk if skip is not None else None, producer_act.noise if producer_act is not None else None)
+        ctx.link = producer_act  # (the caller vouches that this node is x's only consumer)
         ctx.has = (bias is not None, skip is not None, tuple(bias.shape) if bias is not None else None)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
         if passthrough:
@@ -475,13 +479,12 @@ class _ToRGB(torch.autograd.Function):
         ws = wmod if style is not None else (wmod[n_skip:] if n_skip else wmod)
         sts = None if style is None else (style[n_skip:] if n_skip else style)
         gw_full, gw = _zeros_with_tail(b, n_skip, (cin,) if style is not None else (3, cin), x.device)
-        if ctx.actb:
+        if ctx.link is not None:
             # x is the activated output of the StyledConv below: hand that layer its pre-activation gradient and sums directly
             sums3 = torch.empty((b - n_skip, cin, 3), device=x.device, dtype=torch.float32)
             call("w2e_torgb_bwd_actbwd", ptr(xs), ptr(ws), ptr(sts), ptr(gys), ptr(accs), ptr(act_noise), ptr(gxs), ptr(gw), ptr(sums3),
                  b - n_skip, cin, h, w, 0.2, SQRT2, stream_ptr())
-            _PREACT_PENDING.clear()
-            _PREACT_PENDING[id(gx)] = (gx, sums3)
+            ctx.link.gpre, ctx.link.sums = gx, sums3
         elif style is None:
             call("w2e_torgb_bwd_acc", ptr(xs), ptr(ws), ptr(gys), ptr(accs), ptr(gxs), ptr(gw), b - n_skip, cin, h, w, stream_ptr())
         else:

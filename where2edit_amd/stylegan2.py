@@ -321,9 +321,10 @@ class StyledConv(nn.Module):
         s2d = style.reshape(batch, conv.in_channel)
         fwd, bwd, wsq = conv._derived()
         noise_c = noise.contiguous()
+        link = K.ActLink(noise_c) if (torch.is_grad_enabled() and not conv.upsample) else None
         out = K.styled_conv(input, s2d, wsq if conv.demodulate else None, noise_c, self.noise.weight, self.activate.bias, (fwd, bwd),
-                            conv.blur.kernel if conv.upsample else None, conv.upsample)
-        self._act_noise = (noise_c,)
+                            conv.blur.kernel if conv.upsample else None, conv.upsample, link=link)
+        self._act_noise = link
         return out, style
 
 
@@ -342,8 +343,8 @@ class ToRGB(nn.Module):
 
     def forward(self, input, style, skip=None, input_is_stylespace=False, passthrough=False, producer_act=None):
         """`passthrough` (synthesis loop, training): returns (rgb, style, input) -- see functional._ToRGB.  `producer_act`: the
-        `_act_noise` of the fused StyledConv whose output `input` is (pass-through form only): the ToRGB backward then applies
-        that layer's activation backward to the gradient it returns (w2e_torgb_bwd_actbwd)."""
+        ActLink of the fused StyledConv whose output `input` is, when this ToRGB is its only consumer: the ToRGB backward then
+        applies that layer's activation backward to the gradient it returns (w2e_torgb_bwd_actbwd)."""
         conv = self.conv
         batch = input.shape[0]
         style = conv._style(style, batch, input_is_stylespace)
