@@ -189,6 +189,28 @@ int w2e_mask_blend_fwd(const float* a, const float* b, const float* mask, float*
 int w2e_mask_blend_bwd(const float* gout, const float* a, const float* b, const float* mask, float* ga, float* gb,
                        float* gmask, int batch, int channels, int h, int w, int ms, void* stream);
 
+/* ---- K7  the latent mapper MLPs  (mapper/latent_mappers.py:10-82; EqualLinear: model.py:130-164) -----------------------------
+ * LevelsMapper = one Mapper (PixelNorm + 4 x EqualLinear(512, 512, lr_mul, fused_lrelu)) per level of W+; a level ("group") g is
+ * the latent range [l0[g], l0[g] + len[g]) (HOST int arrays, groups <= 4).  Activations are [batch*sum(len), 512] in group-major
+ * row order: row r0_g + b*len[g] + l = latent l0[g] + l of sample b.  Weight arrays are HOST arrays of `groups` device pointers to
+ * [512,512] matrices (row = output feature).  One launch covers one layer of all groups.
+ *   pixelnorm: h = x * rsqrt(mean over the level's latents of x^2 + 1e-8) per (sample, feature) (PixelNorm's dim=1 on a [B,L,512]
+ *              slice, latent_mappers.py:16), x [batch, n_latent, 512], gathered into group-major rows.
+ *   linear, mode 0: out = lrelu(w_scale * a W_g^T + b_scale * bias_g, 0.2) * sqrt2;  scatter != 0: out is [batch, n_latent, 512].
+ *   linear, mode 1: out = w_scale * (a .* lrelu'(y_act)) W_g^T with W_g = the TRANSPOSED weight: the input gradient of a layer whose
+ *                   output was y_act and output gradient a (both group-major).
+ *   wgrad: gw_g = w_scale * gpre^T h_in, gb_g = b_scale * column sums of gpre, gpre = gy .* lrelu'(y); gathered = 0: gy and y are
+ *          [batch, n_latent, 512] (the last layer), else group-major.  Fixed summation order (deterministic).
+ *   gather: [batch, n_latent, 512] -> group-major rows.   transpose: wt[j] = w[j]^T for `count` <= 16 matrices. */
+int w2e_mapper_pixelnorm(const float* x, float* h, int batch, int n_latent, int groups, const int* l0, const int* len, void* stream);
+int w2e_mapper_linear(int mode, const float* a, const float* y_act, float* out, const float* const* w, const float* const* bias,
+                      int batch, int n_latent, int groups, const int* l0, const int* len, float w_scale, float b_scale, int scatter,
+                      void* stream);
+int w2e_mapper_wgrad(const float* gy, const float* y, const float* h_in, float* const* gw, float* const* gb, int batch, int n_latent,
+                     int groups, const int* l0, const int* len, float w_scale, float b_scale, int gathered, void* stream);
+int w2e_mapper_gather(const float* src, float* dst, int batch, int n_latent, int groups, const int* l0, const int* len, void* stream);
+int w2e_mapper_transpose(const float* const* w, int count, float* wt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -544,6 +544,40 @@ def test_capture_refuses_a_step_with_memset_operations():
     coach.train_step(w, lambda feats: torch.sigmoid(feats[6].mean(1, keepdim=True) * 3.0))  # eager: fine
 
 
+@pytest.mark.parametrize("batch,no_medium", [(2, False), (4, False), (8, False), (3, True)])
+def test_levels_mapper_kernels_equal_stock_composition(batch, no_medium, monkeypatch):
+    """mapper_hip: LevelsMapper (PixelNorm over the level's latents + 4 EqualLinear + fused lrelu, per level) as one node on the
+    library's kernels -- the output and every weight / bias gradient against the stock-op composition of the same modules
+    (W2E_MAPPER_STOCK=1), a disabled level included (its latents map to 0)."""
+    from where2edit_amd.latent_mappers import LevelsMapper
+    opts = _opts()
+    opts.no_medium_mapper = no_medium
+    torch.manual_seed(3)
+    m = LevelsMapper(opts).to(DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.ndim == 1:
+                p.normal_(0, 30.0)  # (biases are multiplied by lr_mul = 0.01)
+    x = seeded.wplus_latents(batch, 18, salt=5).to(DEV)
+    r = torch.randn(batch, 18, 512, generator=torch.Generator().manual_seed(1)).to(DEV)
+    names = [n for n, _ in m.named_parameters()]
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        (y * r).sum().backward()
+        return y.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+    y_h, g_h = run()
+    monkeypatch.setenv("W2E_MAPPER_STOCK", "1")
+    y_s, g_s = run()
+    assert_close(y_h, y_s, 1e-5, "mapper output")
+    if no_medium:
+        assert not y_h[:, 4:8].any()
+    for n, a, b in zip(names, g_h, g_s):
+        assert_close(a, b, 2e-5, n)
+
+
 def test_merged_forward_equals_two_passes():
     """Coach.forward_pair runs x = G(w) and x_hat = G(w_hat) as one generator pass over [w; w_hat], with the backward of every
     generator node restricted to the w_hat rows (functional.nograd_prefix).  Same images, losses and mapper gradients as the

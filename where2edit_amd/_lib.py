@@ -20,6 +20,11 @@ _PROTOS = {
     "w2e_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
     "w2e_blur_adjoint_actbwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),
+    "w2e_mapper_pixelnorm": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "w2e_mapper_linear": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P]),
+    "w2e_mapper_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P]),
+    "w2e_mapper_gather": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "w2e_mapper_transpose": (_I, [_P, _I, _P, _P]),
     "w2e_bias_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
     "w2e_bias_act_bwd": (_I, [_P, _P, _P, _L, _F, _F, _P]),
     "w2e_bias_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),

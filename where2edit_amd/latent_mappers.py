@@ -98,6 +98,15 @@ class LevelsMapper(Module):
             self.fine_mapping = Mapper(opts)
 
     def forward(self, x):
+        if x.is_cuda and x.ndim == 3 and x.shape[1] > 8 and not os.environ.get("W2E_MAPPER_STOCK"):
+            # the three MLPs as one node on the library's mapper kernels (forward, weight and bias gradients): mapper_hip.py
+            from . import mapper_hip
+            levels = [(getattr(self, n), l0, ln) for n, off, l0, ln in (("course_mapping", self.opts.no_coarse_mapper, 0, 4),
+                                                                         ("medium_mapping", self.opts.no_medium_mapper, 4, 4),
+                                                                         ("fine_mapping", self.opts.no_fine_mapper, 8, x.shape[1] - 8)) if not off]
+            out = mapper_hip.levels_mlp(x, levels) if levels else None
+            if out is not None:
+                return out
         x_coarse, x_medium, x_fine = x[:, :4, :], x[:, 4:8, :], x[:, 8:, :]
         active = [getattr(self, n) for n, off in (("course_mapping", self.opts.no_coarse_mapper), ("medium_mapping", self.opts.no_medium_mapper),
                                                   ("fine_mapping", self.opts.no_fine_mapper)) if not off]
