@@ -274,6 +274,19 @@ def bench_config5(args, rank, world, device):
     def step():
         return invert_and_edit(imgs, e4e, g, clip, net, text, att, attention_layer=13)
 
+    graph_note, use_graph = None, False
+    if args.graph != "off":  # the fixed-shape pipeline as one hipGraph (about 1500 launches per call: host-bound when enqueued eagerly)
+        try:
+            from where2edit_amd.demo_pipeline import capture_invert_and_edit
+            graphed = capture_invert_and_edit(imgs, e4e, g, clip, net, text, att, attention_layer=13)
+            step = lambda: graphed(imgs, text, att)  # noqa: E731
+            use_graph = True
+        except Exception as e:  # noqa: BLE001
+            if args.graph == "on":
+                raise
+            graph_note = f"eager: capture failed ({type(e).__name__}: {e})"[:300]
+            torch.cuda.synchronize()
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -305,7 +318,7 @@ def bench_config5(args, rank, world, device):
         "config": {"workload": f"e4e encode -> S codes -> 26 features -> region-attention net (cluster-pooled mask, new codes) -> masked "
                                f"FFHQ-1024 generator -> CLIP features (show_demo/try_demo.py:93-157), batch {args.batch}/GPU, no backward",
                    "global_batch": args.batch * world, "parallelism": f"replicas x{world}", "stabilise_steps": n_stab, "stabilised": ok,
-                   "mask_mean": float(out["mask"].mean())}}), flush=True)
+                   "mask_mean": float(out["mask"].mean()), "hip_graph": use_graph, "hip_graph_note": graph_note}}), flush=True)
 
 
 def main():

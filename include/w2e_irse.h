@@ -57,6 +57,10 @@ int w2e_se_apply_bwd(const float* gout, const float* gate, const float* gpool, f
 int w2e_shortcut_add_bwd(float* gx, const float* g, int batch, int channels, int height, int width, int stride, int planar,
                          void* stream);
 
+/* FPN merge of the pSp / e4e encoders (models/encoders/helpers.py:123-140): out [planes,oh,ow] = bilinear up-sampling of
+ * x [planes,ih,iw] (align_corners = True) + y [planes,oh,ow].  Forward only (the encoders are inference networks here). */
+int w2e_upsample_add(const float* x, const float* y, float* out, int64_t planes, int ih, int iw, int oh, int ow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

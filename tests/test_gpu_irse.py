@@ -127,6 +127,20 @@ def test_e4e_encoder_on_hip_matches_reference_fixture():
             assert_close(w2[:1], g[name + ".w"], 1e-4, name + " batch-2, sample 0")
 
 
+@pytest.mark.parametrize("shape,out", [((2, 16, 16, 16), (32, 32)), ((1, 5, 7, 9), (20, 31)), ((3, 8, 32, 32), (64, 64))])
+def test_upsample_add_kernel_equals_bilinear_interpolate(shape, out):
+    """w2e_upsample_add (the encoders' FPN merge, helpers.py:123-140) against F.interpolate(bilinear, align_corners=True) + y."""
+    import torch.nn.functional as F
+    from where2edit_amd.psp_encoders import _upsample_add
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(DEV)
+    y = torch.randn(shape[0], shape[1], *out, generator=g).to(DEV)
+    with torch.no_grad():
+        got = _upsample_add(x, y)
+    ref = F.interpolate(x.double(), size=out, mode="bilinear", align_corners=True) + y.double()
+    assert_close(got, ref, 2e-6, "upsample + add")
+
+
 def test_config5_invert_and_edit_pipeline_matches_oracle():
     """BASELINE configs[4] end to end for one image: e4e -> S codes -> features -> region-attention net -> masked 1024^2
     generator (show_demo/try_demo.py:93-157), every stage against the oracle composition."""
@@ -193,3 +207,11 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
     assert_close(out["img_gen"], gen_o, 1e-4, "edited image")
     assert_close(out["features_gen"], fo, 1e-3, "CLIP features of the edit")
     assert_close(gaussian_blur5(out["mask"]), OA.gaussian_blur5(mask_o), 1e-5, "blur")
+    # the same pipeline replayed as one hipGraph, on new inputs copied into its static buffers
+    from where2edit_amd.demo_pipeline import capture_invert_and_edit
+    clip_dev = CLIPLoss(opts, model=clip).to(DEV)
+    run = capture_invert_and_edit(torch.zeros_like(img).to(DEV), e4e, g, clip_dev, net, torch.zeros_like(text).to(DEV), torch.zeros_like(att_text).to(DEV),
+                                  attention_layer=att)
+    rep = run(img.to(DEV), text.to(DEV), att_text.to(DEV))
+    for key in ("latents", "img_orig", "mask", "img_gen", "features_gen"):
+        assert_close(rep[key], out[key], 1e-5, f"graph replay: {key}")  # (split-K joins by fp32 atomics: run-to-run rounding)

@@ -138,6 +138,30 @@ __global__ void shortcut_add_bwd_kernel(float* __restrict__ gx, const float* __r
 
 using namespace w2e;
 
+
+// FPN merge of the pSp / e4e encoders (models/encoders/helpers.py:123-140): out = bilinear(x -> (oh, ow), align_corners=True) + y.
+// One thread per output element: the four source values come from the small (cache-resident) map, y and out stream once.
+namespace w2e {
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                                          int ih, int iw, int oh, int ow, float sy, float sx, int64_t total) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+        const int ox = (int)(e % ow);
+        const int64_t t = e / ow;
+        const int oy = (int)(t % oh);
+        const int64_t plane = t / oh;
+        const float fy = oy * sy, fx = ox * sx;  // align_corners: src = dst * (in - 1) / (out - 1)
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + 1 < ih ? y0 + 1 : ih - 1, x1 = x0 + 1 < iw ? x0 + 1 : iw - 1;
+        const float wy = fy - y0, wx = fx - x0;
+        const float* xp = x + plane * ih * iw;
+        const float top = xp[y0 * iw + x0] * (1.f - wx) + xp[y0 * iw + x1] * wx;
+        const float bot = xp[y1 * iw + x0] * (1.f - wx) + xp[y1 * iw + x1] * wx;
+        out[e] = top * (1.f - wy) + bot * wy + y[e];
+    }
+}
+}  // namespace w2e
+
 extern "C" {
 
 int w2e_affine_act_fwd(const float* x, const float* a, const float* b, const float* slope, float* y, int batch, int channels,
@@ -212,6 +236,17 @@ int w2e_shortcut_add_bwd(float* gx, const float* g, int batch, int channels, int
     if (total == 0) return 0;
     shortcut_add_bwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gx, g, height, width, stride, planar, total);
     W2E_LAUNCH_CHECK("shortcut_add_bwd");
+    return 0;
+}
+
+int w2e_upsample_add(const float* x, const float* y, float* out, int64_t planes, int ih, int iw, int oh, int ow, void* stream) {
+    W2E_REQUIRE(x && y && out, "upsample_add: null tensor");
+    W2E_REQUIRE(planes >= 0 && ih > 0 && iw > 0 && oh > 0 && ow > 0, "upsample_add: bad dims");
+    const int64_t total = planes * oh * ow;
+    if (total == 0) return 0;
+    const float sy = oh > 1 ? (float)(ih - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(iw - 1) / (float)(ow - 1) : 0.f;
+    w2e::upsample_add_kernel<<<w2e::stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, out, ih, iw, oh, ow, sy, sx, total);
+    W2E_LAUNCH_CHECK("upsample_add");
     return 0;
 }
 

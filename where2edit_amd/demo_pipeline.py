@@ -51,3 +51,40 @@ def invert_and_edit(images, e4e, g_ema, clip_loss, mapper, text_features, attent
     feat_gen = clip_loss.model.encode_image(clip_loss.preprocess(img_gen))
     return {"img_orig": img_orig, "img_gen": img_gen, "mask": mask, "latents": latents, "new_codes": new_codes,
             "features_orig": feat_orig, "features_gen": feat_gen}
+
+
+def capture_invert_and_edit(images, e4e, g_ema, clip_loss, mapper, text_features, attention_text_features, *, warmup=3, **kw):
+    """The fixed-shape pipeline as ONE hipGraph: returns `run(images, text_features, attention_text_features) -> dict` that copies
+    the inputs into static buffers, replays the graph and returns the (static) output tensors.  About 1500 launches per call are
+    otherwise enqueued eagerly and the pipeline is host-bound (40 ms of kernels in 52 ms of wall time at batch 8).  As for
+    Coach.capture_step, a pipeline that issues memset operations is refused (they are not replayed reliably on this ROCm stack)."""
+    static = [images.clone(), text_features.clone(), attention_text_features.clone()]
+
+    def body():
+        return invert_and_edit(static[0], e4e, g_ema, clip_loss, mapper, static[1], static[2], **kw)
+
+    side = torch.cuda.Stream(device=images.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
+        body()
+        torch.cuda.synchronize()
+    memsets = sorted({e.name for e in prof.events() if any("emset" in k.name or "fillBuffer" in k.name for k in (e.kernels or []))})
+    if memsets:
+        raise RuntimeError(f"capture_invert_and_edit: the pipeline issues memset operations (from {', '.join(memsets)})")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = body()
+
+    def run(images_new, text_new, attention_text_new):
+        static[0].copy_(images_new), static[1].copy_(text_new), static[2].copy_(attention_text_new)
+        graph.replay()
+        return out
+
+    run.graph = graph
+    return run
+

@@ -22,6 +22,7 @@ PROTOS = {
     "w2e_se_apply_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "w2e_se_apply_bwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
     "w2e_shortcut_add_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "w2e_upsample_add": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
 }
 
 
