@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "../../include/w2e_irse.h"  // w2e_affine_act_fwd: the bias + PReLU pass after a split launch
 
 namespace w2e {
 
@@ -1033,9 +1034,15 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int wp2 = next_pow2(w);
     int best = -1, best_splits = 1;
     double best_cost = 0.0;
-    // no split-K with the bias/PReLU epilogue (it needs the complete sum) nor in deterministic mode (no fp32 atomics): the
-    // tile is then chosen among the unsplit candidates, not chosen for a split and stripped of it afterwards
-    const int sp_max = (prelu || opt.deterministic) ? 1 : 32;
+    // no split-K in deterministic mode (no fp32 atomics): the tile is then chosen among the unsplit candidates, not chosen for a
+    // split and stripped of it afterwards
+    // (a split bias/PReLU launch is followed by one elementwise pass, like the split activation: worth it only where even the
+    // smallest tile, 64 channels x 64 pixels, leaves CUs without a workgroup -- measured on the IR-SE50 / style-head shapes)
+    int sp_max = opt.deterministic ? 1 : 32;
+    if (prelu) {
+        const int tw6 = wp2 < 32 ? wp2 : 32, th6 = 64 / tw6 > 0 ? 64 / tw6 : 1;
+        if ((int64_t)batch * ceil_div(n_ch, 64) * ceil_div(h, th6) * ceil_div(w, tw6) >= 256) sp_max = 1;
+    }
     for (int c = 0; c < ncfg; ++c) {
         const int tn = 32 * cfgs[c].nob * cfgs[c].wo, tm = 32 * cfgs[c].npb * cfgs[c].wp;
         const int tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
@@ -1128,7 +1135,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
         const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
         if (fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
-    if (opt.deterministic || prelu) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
+    if (opt.deterministic) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
@@ -1247,7 +1254,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
             if (dot_with) ok = launch_mode_dma<W2E_CONV_DOWN, EPI_DOT, 8>(best, p, (int)grid, lds, s);
             else ok = launch_mode_dma<W2E_CONV_DOWN, EPI_PLAIN, 8>(best, p, (int)grid, lds, s);
         }
-    } else if (prelu) {
+    } else if (prelu && p.splits == 1) {
         if (mode == W2E_CONV_SAME) ok = launch_mode<W2E_CONV_SAME, EPI_PRELU, 8>(best, p, (int)grid, lds, s);
         else ok = launch_mode<W2E_CONV_DOWN, EPI_PRELU, 8>(best, p, (int)grid, lds, s);
     } else if (mode == W2E_CONV_SAME) {
@@ -1291,6 +1298,11 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
 #endif
     if (act && p.splits > 1) {  // the activation needs the complete sum: one in-place elementwise pass
         const int rc = w2e_bias_act_fwd(y, bias, noise, noise_w, y, batch, n_ch, (int64_t)h * w, 0.2f, 1.4142135623730951f, stream);
+        if (rc != 0) return rc;
+    }
+    if (prelu && p.splits > 1) {  // likewise bias + PReLU (the low-resolution layers of IR-SE50 and of the encoders' style heads: a
+                                  // handful of tiles with a K*9/2-long MFMA chain each unless K is split)
+        const int rc = w2e_affine_act_fwd(y, nullptr, bias, slope, y, batch, n_ch, (int64_t)p.out_h * p.out_w, stream);
         if (rc != 0) return rc;
     }
     return 0;
