@@ -44,6 +44,15 @@ int w2e_affine_act_bwd(const float* gy, const float* y, const float* a, const fl
  * backward, the gradient reaching the gate.  One wave per (b,c) plane, fixed reduction order. */
 int w2e_channel_sums(const float* x, const float* y, float* sums, int batch, int channels, int64_t hw, void* stream);
 
+/* The SE gate on the pooled sums (helpers.py:56-72): gate[b,c] = sigmoid(fc2 . relu(fc1 . (sums[b,:] * inv_hw))), with
+ * fc1 [R,C] and fc2 [C,R] the two bias-free 1x1 convolutions (R = C / reduction); hidden [B,R] receives the ReLU output
+ * (kept for the backward).  One workgroup per sample, fixed reduction order. */
+int w2e_se_gate_fwd(const float* sums, const float* fc1, const float* fc2, float* gate, float* hidden, int batch, int channels,
+                    int reduced, float inv_hw, void* stream);
+/* Its adjoint: dgate[b,c] (= w2e_channel_sums(gout, t)) -> gpool[b,c], the gradient at the pooled mean times inv_hw. */
+int w2e_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* fc1, const float* fc2, float* gpool,
+                    int batch, int channels, int reduced, float inv_hw, void* stream);
+
 /* out[b,c,p] = t[b,c,p]*gate[b,c] + shortcut  (helpers.py:72 + :118-119 `res + shortcut`).
  * sc_stride = 0: shortcut is a [B,C,H,W] tensor; sc_stride = s >= 1: shortcut is x[b,c,s*y,s*x] of a [B,C,s*H,s*W]
  * tensor (MaxPool2d(1, s), helpers.py:100-101). */

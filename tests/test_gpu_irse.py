@@ -32,6 +32,24 @@ def test_conv3x3_same_with_folded_bn_and_prelu(b, k, n, h, w):
     assert_close(y, F.conv2d(x.double(), wt.double(), padding=1) + bias.double()[None, :, None, None], 1e-4, "conv + bias")
 
 
+@pytest.mark.parametrize("b,c,r,hw", [(3, 64, 4, 56 * 56), (2, 512, 32, 49), (1, 40, 5, 9)])
+def test_se_gate_kernels_equal_the_stock_composition(b, c, r, hw):
+    """w2e_se_gate_fwd / _bwd against mean -> fc1 -> ReLU -> fc2 -> sigmoid and its autograd gradient (helpers.py:56-72) in float64."""
+    from where2edit_amd import irse_hip as I
+    g = torch.Generator().manual_seed(c + r)
+    plan = types.SimpleNamespace(depth=c, fc1=(torch.randn(r, c, generator=g) * c ** -0.5).to(DEV), fc2=torch.randn(c, r, generator=g).to(DEV))
+    sums, dgate = torch.randn(b, c, generator=g) * hw, torch.randn(b, c, generator=g)
+    gate, hidden = I.UnitPlan.gate(plan, sums.to(DEV), 1.0 / hw)
+    pooled = (sums.double() / hw).requires_grad_(True)
+    h_ref = torch.relu(pooled @ plan.fc1.double().cpu().t())
+    g_ref = torch.sigmoid(h_ref @ plan.fc2.double().cpu().t())
+    assert_close(hidden, h_ref, 1e-5, "SE hidden")
+    assert_close(gate, g_ref, 1e-5, "SE gate")
+    (gp_ref,) = torch.autograd.grad(g_ref, pooled, dgate.double())
+    gpool = I.UnitPlan.gate_bwd(plan, dgate.to(DEV), gate, hidden, 1.0 / hw)
+    assert_close(gpool, gp_ref / hw, 1e-5, "SE gate backward")
+
+
 @pytest.mark.parametrize("b,k,n,h", [(2, 64, 64, 28), (1, 40, 72, 9), (2, 256, 512, 7)])
 def test_conv3x3_stride2_pad1_and_its_adjoint(b, k, n, h):
     """DOWN with down_pad = nn.Conv2d(k, n, 3, 2, 1) on a [b,k,2h,2h] input; UP + the (+1,+1) crop = its input gradient."""

@@ -88,6 +88,67 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
     if (lane == 0) sums[plane] = acc;
 }
 
+// The SE block's gate (helpers.py:56-72) on the pooled [B,C] sums: mean -> fc1 (1x1 conv, no bias) -> ReLU -> fc2 -> sigmoid.
+// One workgroup per sample: C <= a few hundred channels, R = C/16 hidden units -- one launch instead of the mean /
+// two rocBLAS GEMMs of B rows / ReLU / sigmoid.  `hidden` keeps the ReLU output for the backward.
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ sums, const float* __restrict__ fc1,
+                                                          const float* __restrict__ fc2, float* __restrict__ gate,
+                                                          float* __restrict__ hidden, int C, int R, float inv_hw) {
+    extern __shared__ float se_sm[];
+    float* pooled = se_sm;    // [C]
+    float* hid = se_sm + C;   // [R]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) pooled[c] = sums[(int64_t)b * C + c] * inv_hw;
+    __syncthreads();
+    for (int r = wave; r < R; r += 4) {  // one wave per hidden unit, fixed reduction order
+        const float* w = fc1 + (int64_t)r * C;
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w[c] * pooled[c];
+        acc = wave_sum_irse(acc);
+        if (lane == 0) {
+            acc = acc > 0.f ? acc : 0.f;
+            hid[r] = acc;
+            hidden[(int64_t)b * R + r] = acc;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float* w = fc2 + (int64_t)c * R;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += w[r] * hid[r];
+        gate[(int64_t)b * C + c] = 1.f / (1.f + expf(-acc));
+    }
+}
+
+// Its adjoint: dgate[b,c] = sum_p gout*t (w2e_channel_sums) -> through the sigmoid, fc2, the ReLU and fc1 -> the gradient
+// at the pooled mean, divided by H*W (what every pixel of the plane receives, w2e_se_apply_bwd's gpool).
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                          const float* __restrict__ hidden, const float* __restrict__ fc1,
+                                                          const float* __restrict__ fc2, float* __restrict__ gpool, int C, int R,
+                                                          float inv_hw) {
+    extern __shared__ float se_sm[];
+    float* d2 = se_sm;       // [C] gradient at the sigmoid's input
+    float* dh = se_sm + C;   // [R] gradient at the ReLU's input
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        const float g = gate[(int64_t)b * C + c];
+        d2[c] = dgate[(int64_t)b * C + c] * g * (1.f - g);
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += fc2[(int64_t)c * R + r] * d2[c];
+        acc = wave_sum_irse(acc);
+        if (lane == 0) dh[r] = hidden[(int64_t)b * R + r] > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += fc1[(int64_t)r * C + c] * dh[r];
+        gpool[(int64_t)b * C + c] = acc * inv_hw;
+    }
+}
+
 __global__ void se_apply_fwd_kernel(const float* __restrict__ t, const float* __restrict__ gate, const float* __restrict__ sc,
                                     int sc_stride, float* __restrict__ out, int H, int W, int64_t total) {
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
@@ -202,6 +263,28 @@ int w2e_channel_sums(const float* x, const float* y, float* sums, int batch, int
     W2E_REQUIRE(al || (hw & 3), "channel_sums: float4 path needs 16-byte aligned tensors");
     channel_sums_kernel<<<(unsigned)ceil_div(planes, 4), 256, 0, (hipStream_t)stream>>>(x, y, sums, planes, hw);
     W2E_LAUNCH_CHECK("channel_sums");
+    return 0;
+}
+
+int w2e_se_gate_fwd(const float* sums, const float* fc1, const float* fc2, float* gate, float* hidden, int batch, int channels,
+                    int reduced, float inv_hw, void* stream) {
+    W2E_REQUIRE(sums && fc1 && fc2 && gate && hidden, "se_gate_fwd: null tensor");
+    W2E_REQUIRE(batch >= 0 && channels > 0 && reduced > 0 && channels + reduced <= 8192, "se_gate_fwd: bad dims");
+    if (batch == 0) return 0;
+    se_gate_fwd_kernel<<<(unsigned)batch, 256, sizeof(float) * (size_t)(channels + reduced), (hipStream_t)stream>>>(
+        sums, fc1, fc2, gate, hidden, channels, reduced, inv_hw);
+    W2E_LAUNCH_CHECK("se_gate_fwd");
+    return 0;
+}
+
+int w2e_se_gate_bwd(const float* dgate, const float* gate, const float* hidden, const float* fc1, const float* fc2, float* gpool,
+                    int batch, int channels, int reduced, float inv_hw, void* stream) {
+    W2E_REQUIRE(dgate && gate && hidden && fc1 && fc2 && gpool, "se_gate_bwd: null tensor");
+    W2E_REQUIRE(batch >= 0 && channels > 0 && reduced > 0 && channels + reduced <= 8192, "se_gate_bwd: bad dims");
+    if (batch == 0) return 0;
+    se_gate_bwd_kernel<<<(unsigned)batch, 256, sizeof(float) * (size_t)(channels + reduced), (hipStream_t)stream>>>(
+        dgate, gate, hidden, fc1, fc2, gpool, channels, reduced, inv_hw);
+    W2E_LAUNCH_CHECK("se_gate_bwd");
     return 0;
 }
 

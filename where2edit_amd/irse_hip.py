@@ -1,7 +1,7 @@
 """The IR-SE50 ArcFace body (models/facial_recognition/model_irse.py:9-48, helpers.py:56-119) on the hand-written
 kernels (include/w2e_irse.h): every 3x3 / shortcut convolution runs on the fp32-MFMA engine of the StyleGAN2 layers
 (w2e_conv3x3) with eval-mode BatchNorm folded into its scales and bias and PReLU in its epilogue; the SE block is a
-one-wave-per-plane pooling kernel, a [B,C]-sized MLP on rocBLAS, and a gate-and-add kernel.
+one-wave-per-plane pooling kernel, a one-workgroup-per-sample gate kernel (fc1 / ReLU / fc2 / sigmoid) and a gate-and-add kernel.
 
 Eval mode only (criteria/id_loss.py:14 calls facenet.eval()) and frozen weights: forward + INPUT gradients, which is what
 the identity loss needs (the gradient flows back to the generated image).  One autograd node per bottleneck unit."""
@@ -14,11 +14,14 @@ from ._lib import call, ptr, stream_ptr
 _I = __import__("ctypes").c_int
 _P = __import__("ctypes").c_void_p
 _L = __import__("ctypes").c_int64
+_F = __import__("ctypes").c_float
 PROTOS = {
     "w2e_conv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "w2e_affine_act_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "w2e_affine_act_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "w2e_channel_sums": (_I, [_P, _P, _P, _I, _I, _L, _P]),
+    "w2e_se_gate_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "w2e_se_gate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "w2e_se_apply_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "w2e_se_apply_bwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
     "w2e_shortcut_add_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -33,10 +36,14 @@ def declare(lib):
 
 
 # ---------------------------------------------------------------------------------------------- raw kernel calls
-def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None):
-    """w2e_conv3x3.  h,w: input size for SAME / UP, output size for DOWN.  in_scale [B,K] / out_scale [B,N] / bias, slope [N]."""
+def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None, out=None):
+    """w2e_conv3x3.  h,w: input size for SAME / UP, output size for DOWN.  in_scale [B,K] / out_scale [B,N] / bias, slope [N].
+    `out`: a contiguous [B,n_out,h,w] tensor to write (SAME / DOWN)."""
     b, k = x.shape[0], x.shape[1]
-    if mode == K.MODE_UP:
+    if out is not None:
+        assert mode != K.MODE_UP and out.shape == (b, n_out, h, w) and out.is_contiguous()
+        y = out
+    elif mode == K.MODE_UP:
         y = torch.empty((b, n_out, 2, 2, h + 1, (w + 4) & ~3), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
@@ -101,8 +108,21 @@ class UnitPlan:
             raise RuntimeError("IR-SE50 on the HIP kernels needs positive PReLU slopes (the backward reads the branch from the sign "
                                "of the output); this checkpoint has a non-positive one")
 
-    def gate(self, pooled):
-        return torch.sigmoid(torch.relu(pooled @ self.fc1.t()) @ self.fc2.t())  # [B,C]-sized (helpers.py:66-71)
+    def gate(self, sums, inv_hw):
+        """(gate [B,C], hidden [B,R]) of the SE block from the per-plane sums (helpers.py:66-71): one launch."""
+        b, r = sums.shape[0], self.fc1.shape[0]
+        gate = torch.empty((b, self.depth), device=sums.device, dtype=torch.float32)
+        hidden = torch.empty((b, r), device=sums.device, dtype=torch.float32)
+        call("w2e_se_gate_fwd", ptr(sums), ptr(self.fc1), ptr(self.fc2), ptr(gate), ptr(hidden), b, self.depth, r, float(inv_hw), stream_ptr())
+        return gate, hidden
+
+    def gate_bwd(self, dgate, gate, hidden, inv_hw):
+        """gradient at the pooled mean, already divided by H*W (what w2e_se_apply_bwd adds to every pixel of the plane)"""
+        b, r = dgate.shape[0], self.fc1.shape[0]
+        gpool = torch.empty_like(dgate)
+        call("w2e_se_gate_bwd", ptr(dgate), ptr(gate), ptr(hidden), ptr(self.fc1), ptr(self.fc2), ptr(gpool), b, self.depth, r, float(inv_hw),
+             stream_ptr())
+        return gpool
 
 
 _REP = {}
@@ -138,7 +158,7 @@ class _IRUnit(torch.autograd.Function):
             t2 = conv3x3(t1, p.w2f, p.depth, h, w, out_scale=a2, bias=p.b2)              # conv + BN2 (:114-115)
         else:
             t2 = conv3x3(t1, p.w2f, p.depth, oh, ow, mode=K.MODE_DOWN, down_pad=1, out_scale=a2, bias=p.b2)
-        gate = p.gate(channel_sums(t2) / float(oh * ow))                                 # SE (:56-72)
+        gate, hidden = p.gate(channel_sums(t2), 1.0 / float(oh * ow))                    # SE (:56-72)
         out = torch.empty_like(t2)
         if p.conv_shortcut:
             a_s = _rep(p.a_s, b)
@@ -150,28 +170,23 @@ class _IRUnit(torch.autograd.Function):
         else:  # MaxPool2d(1, stride): the strided samples of x (:100-101)
             call("w2e_se_apply_fwd", ptr(t2), ptr(gate), ptr(x), s, ptr(out), b, p.depth, oh, ow, stream_ptr())
         ctx.plan, ctx.geom = plan, (n_grad if n_grad is not None else b, cin, h, w, oh, ow)
-        ctx.save_for_backward(t1, t2, gate)
+        ctx.save_for_backward(t1, t2, gate, hidden)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        t1, t2, gate = ctx.saved_tensors
+        t1, t2, gate, hidden = ctx.saved_tensors
         p = ctx.plan
         n, cin, h, w, oh, ow = ctx.geom
         s = p.stride
         full = gout.shape[0]
         gout = (gout if gout.is_contiguous() else gout.contiguous())[:n]
-        t1, t2, gate = t1[:n], t2[:n], gate[:n]
-        # SE backward: d gate = sum_p gout*t2; through sigmoid / fc2 / relu / fc1 on [n,C] tensors; back to the mean
-        dgate = channel_sums(gout, t2)
-        with torch.enable_grad():
-            pooled = (channel_sums(t2) / float(oh * ow)).requires_grad_(True)
-            g2 = p.gate(pooled)
-            (gpool,) = torch.autograd.grad(g2, pooled, dgate)
-        gpool = (gpool / float(oh * ow)).contiguous()
+        t1, t2, gate, hidden = t1[:n], t2[:n], gate[:n], hidden[:n]  # leading rows of contiguous tensors: contiguous
+        # SE backward: d gate = sum_p gout*t2, then through sigmoid / fc2 / ReLU / fc1 back to the mean (one launch)
+        gpool = p.gate_bwd(channel_sums(gout, t2), gate, hidden, 1.0 / float(oh * ow))
         g_t2 = torch.empty_like(gout)
-        call("w2e_se_apply_bwd", ptr(gout), ptr(gate.contiguous()), ptr(gpool), ptr(g_t2), n, p.depth, oh * ow, stream_ptr())
+        call("w2e_se_apply_bwd", ptr(gout), ptr(gate), ptr(gpool), ptr(g_t2), n, p.depth, oh * ow, stream_ptr())
         a2 = _rep(p.a2, n)
         if s == 1:
             g_t1 = conv3x3(g_t2, p.w2b, p.depth, h, w, in_scale=a2)
@@ -179,7 +194,11 @@ class _IRUnit(torch.autograd.Function):
         else:  # adjoint of the padded stride-2 conv: UP, then the (+1,+1) crop folded into the PReLU backward
             tt = conv3x3(g_t2, p.w2b, p.depth, oh, ow, mode=K.MODE_UP, in_scale=a2)
             g_c1 = affine_act_bwd(tt, t1, None, p.slope, n, p.depth, h, w, planar=True)
-        gx = conv3x3(g_c1, p.w1b, cin, h, w, out_scale=_rep(p.a1, n))
+        # the samples past n take no gradient: the convolution writes the head of a full-batch tensor, the tail is zeroed
+        gx_full = torch.empty((full, cin, h, w), device=gout.device, dtype=torch.float32)
+        gx = conv3x3(g_c1, p.w1b, cin, h, w, out_scale=_rep(p.a1, n), out=gx_full[:n])
+        if n < full:
+            gx_full[n:].zero_()
         if p.conv_shortcut:
             a_s = _rep(p.a_s, n)
             if s == 1:
@@ -190,9 +209,7 @@ class _IRUnit(torch.autograd.Function):
                 call("w2e_shortcut_add_bwd", ptr(gx), ptr(ts), n, cin, h, w, 1, 1, stream_ptr())
         else:
             call("w2e_shortcut_add_bwd", ptr(gx), ptr(gout), n, cin, oh, ow, s, 0, stream_ptr())
-        if n < full:  # the rest of the batch takes no gradient
-            gx = torch.cat([gx, torch.zeros((full - n, cin, h, w), device=gx.device, dtype=torch.float32)])
-        return gx, None, None
+        return gx_full, None, None
 
 
 class _InputLayer(torch.autograd.Function):
@@ -214,10 +231,11 @@ class _InputLayer(torch.autograd.Function):
         plan, n = ctx.plan, ctx.n
         full, _, h, w = y.shape
         g = affine_act_bwd((gy if gy.is_contiguous() else gy.contiguous())[:n], y[:n], plan["a"], plan["slope"], n, 64, h, w)
-        gx = conv3x3(g, plan["wb"], 3, h, w)
+        gx_full = torch.empty((full, 3, h, w), device=g.device, dtype=torch.float32)
+        conv3x3(g, plan["wb"], 3, h, w, out=gx_full[:n])
         if n < full:
-            gx = torch.cat([gx, torch.zeros((full - n, 3, h, w), device=gx.device, dtype=torch.float32)])
-        return gx, None, None
+            gx_full[n:].zero_()
+        return gx_full, None, None
 
 
 class BackbonePlan:
