@@ -52,6 +52,11 @@ typedef struct {
     int channels, res;
 } w2e_att_source;
 
+/* The demodulation coefficients of every source in one launch (model.py:244-246 for the [32,C,1,1] weights):
+ *   sources[j].demod[b,o] = rsqrt( sum_i (wscaled_j[i,o] * style_j[b,i])^2 + eps )      (written; [B,32] per source)
+ * Reads only wscaled / style / channels of each descriptor.  Deterministic. */
+int w2e_attention_demod(const w2e_att_source* sources, int n_sources, int batch, float eps, void* stream);
+
 /* each[b,p] = sigmoid( lrelu( d_last[b] * sum_{j,o} wlast[32j+o] * s_last[b,32j+o] * a_j[b,o,p] + nw_last*noise_last[b,p]
  *                              + bias_last ) * sqrt2 + initial_bias )
  * sources: HOST array of n_sources descriptors (copied into the launch).  wlast = scale*W of attention_last [32*n],

@@ -289,6 +289,51 @@ def test_bench_workload2_step_matches_oracle(capfd):
     assert_grad_close(flat_h, flat_o, "mapper gradients at the measured configuration")
 
 
+def test_bench_workload3_step_matches_oracle():
+    """BASELINE configs[2] at the bench's own configuration, as one step: bench.py's workload 3 -- FFHQ-1024, the blend at layer 13
+    (64x64) with the mask the region-attention net's mask branch computes from the unedited pass's activations (cluster-pooled,
+    thresholded, blurred), clip_loss on the full ViT-B/32, id_loss through IR-SE50 (id_lambda 0.1), latent L2 -- against the oracle
+    fed with the SAME mask (the mask branch has its own oracle tests, test_gpu_attention.py; a hard threshold is no place for a
+    tolerance): every loss term and the mapper gradients.  Batch 2 (the CPU oracle's 1024^2 backward takes ~15 s per image)."""
+    import bench
+    from oracle import clip_model as OC
+    from oracle import irse as OI
+    from oracle import mappers as OM
+    size, batch = 1024, 2
+    coach = bench.build_coach(size, batch, DEV, False, "hip", 3)
+    isd = seeded.irse_fill(coach.id_loss.facenet.state_dict())
+    coach.id_loss.facenet.load_state_dict(isd, strict=True)
+    w = bench.synthetic_latents(coach.net.decoder, batch, 0)
+    mask_fn = bench.make_mask(coach, batch, size, 0, DEV, False)
+    # the parameters the step starts from (train_step ends with the Ranger update; the gradients stay in .grad)
+    osd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in coach.net.mapper.state_dict().items()}
+    d = coach.train_step(w, mask_fn)
+    mask = mask_fn.last.detach().cpu()
+    assert mask.shape == (batch, 1, 64, 64) and 0.02 < float(mask.mean()) < 0.98, (mask.shape, float(mask.mean()))
+    gsd = {k: v.detach().cpu() for k, v in coach.net.decoder.state_dict().items()}
+    csd = {k: v.detach().cpu() for k, v in coach.clip_loss.model.state_dict().items()}
+    isd = {k: v.detach().cpu() for k, v in isd.items()}
+    params = dict(coach.net.mapper.named_parameters())
+    tokens, wc = coach.text_inputs.cpu(), w.cpu()
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    with torch.no_grad():
+        x_o, _, _, feats_o = OG.generator_forward(gsd, [wc], size=size, input_is_latent=True, randomize_noise=False, return_features=True)
+    wh_o = wc + 0.1 * OM.levels_mapper(osd, wc)
+    xh_o, wh_o, _ = OG.generator_forward(gsd, [wh_o], size=size, input_is_latent=True, randomize_noise=False, return_latents=True,
+                                         attention_layer=13, attention_map=mask, feature_map=feats_o)
+    l_id = OI.id_loss(isd, xh_o, x_o)
+    l_clip = OC.clip_loss(csd, xh_o, tokens, size).mean()
+    l_l2 = torch.nn.functional.mse_loss(wh_o, wc)
+    loss_o = 0.1 * l_id + l_clip + 0.8 * l_l2
+    names = list(osd)
+    grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
+    for key, ref in (("loss_id", l_id), ("loss_clip", l_clip), ("loss_l2_latent", l_l2), ("loss", loss_o)):
+        assert abs(float(d[key]) - ref.item()) <= 2e-4 * max(abs(ref.item()), 1e-3), (key, float(d[key]), ref.item())
+    flat_h = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
+    flat_o = torch.cat([g.reshape(-1) for g in grads_o])
+    assert_grad_close(flat_h, flat_o, "mapper gradients of the config-3 step at 1024^2")
+
+
 def _region_id_setup(size, s_space=False):
     from where2edit_amd.attention_model import Generator as AttentionGenerator
     from where2edit_amd.id_loss import IDLoss

@@ -127,6 +127,39 @@ __global__ __launch_bounds__(256) void cluster_accumulate_kernel(const float* __
     }
 }
 
+// Demodulation coefficients of every source's modulated 1x1 conv (model.py:244-246 with a [32,C,1,1] weight) in one launch:
+// d_j[b,o] = rsqrt(sum_i (wscaled_j[i,o] * style_j[b,i])^2 + eps).  grid (source, batch); thread = (output o, one of 8 channel
+// residues); fixed reduction order.
+struct AttDemodLaunch {
+    const float* wscaled[W2E_ATT_MAX_SOURCES];
+    const float* style[W2E_ATT_MAX_SOURCES];
+    float* demod[W2E_ATT_MAX_SOURCES];
+    int channels[W2E_ATT_MAX_SOURCES];
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void att_demod_kernel(const AttDemodLaunch L) {
+    __shared__ float part[8][32];
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int o = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int C = L.channels[j];
+    const float* w = L.wscaled[j];
+    const float* st = L.style[j] + (int64_t)b * C;
+    float acc = 0.f;
+    for (int i = r; i < C; i += 8) {
+        const float v = w[i * 32 + o] * st[i];
+        acc += v * v;
+    }
+    part[r][o] = acc;
+    __syncthreads();
+    if (r == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][o];
+        L.demod[j][(int64_t)b * 32 + o] = rsqrtf(t + L.eps);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- attention logits
 struct AttLaunch {
     w2e_att_source src[W2E_ATT_MAX_SOURCES];
@@ -313,6 +346,23 @@ extern "C" int w2e_cluster_accumulate(const float* feat, const int32_t* assign, 
     else if (clusters <= 16) cluster_accumulate_kernel<16><<<grid, 256, 0, s>>>(feat, assign, partial, counts, channels, pos_channels, size, clusters);
     else cluster_accumulate_kernel<32><<<grid, 256, 0, s>>>(feat, assign, partial, counts, channels, pos_channels, size, clusters);
     W2E_LAUNCH_CHECK("cluster_accumulate");
+    return 0;
+}
+
+extern "C" int w2e_attention_demod(const w2e_att_source* sources, int n_sources, int batch, float eps, void* stream) {
+    W2E_REQUIRE(sources, "attention_demod: null sources");
+    W2E_REQUIRE(n_sources >= 1 && n_sources <= W2E_ATT_MAX_SOURCES, "attention_demod: 1 <= n_sources <= %d", W2E_ATT_MAX_SOURCES);
+    W2E_REQUIRE(batch >= 0 && batch < 65536 && eps > 0.f, "attention_demod: bad dims");
+    if (batch == 0) return 0;
+    AttDemodLaunch L{};
+    for (int j = 0; j < n_sources; ++j) {
+        const w2e_att_source& s = sources[j];
+        W2E_REQUIRE(s.wscaled && s.style && s.demod && s.channels > 0, "attention_demod: source %d: null tensor or bad dims", j);
+        L.wscaled[j] = s.wscaled, L.style[j] = s.style, L.demod[j] = const_cast<float*>(s.demod), L.channels[j] = s.channels;
+    }
+    L.eps = eps;
+    att_demod_kernel<<<dim3((unsigned)n_sources, (unsigned)batch), 256, 0, (hipStream_t)stream>>>(L);
+    W2E_LAUNCH_CHECK("attention_demod");
     return 0;
 }
 

@@ -45,6 +45,7 @@ PROTOS = {
     "w2e_cluster_accumulate": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "w2e_attention_logits": (ctypes.c_int, [ctypes.POINTER(_AttSource), ctypes.c_int] + [ctypes.c_void_p] * 9 +
                              [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "w2e_attention_demod": (ctypes.c_int, [ctypes.POINTER(_AttSource), ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "w2e_cluster_pool": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p]),
 }
 
@@ -184,6 +185,31 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
             cache[id(conv)] = hit
         return hit[1]
 
+    def _text_styles(self, mods, attention_text):
+        """[aff(attention_text) for aff in mods] (the per-source style EqualLinears, :798 / :826, and attention_textca_last) from ONE
+        launch of the generator's stacked-affine kernel (w2e_style_affine_fwd); None when the layers are not plain frozen
+        EqualLinears of 32-multiple widths (the caller then evaluates them one by one)."""
+        from . import functional as K
+        if any(not isinstance(m, EqualLinear) or m.bias is None or m.activation or m.weight.shape[0] % 32 for m in mods):
+            return None
+        if torch.is_grad_enabled() and any(m.weight.requires_grad or m.bias.requires_grad for m in mods):
+            return None
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        cache = self.__dict__.get("_text_pack")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.cat([m.weight.detach().float() * m.scale for m in mods]).contiguous()
+                b = torch.cat([m.bias.detach().float() * m.lr_mul for m in mods]).contiguous()
+                meta, off = [], 0
+                for m in mods:
+                    cw = m.weight.shape[0]
+                    meta.append(torch.stack([torch.zeros(cw, dtype=torch.long), torch.full((cw,), off), torch.full((cw,), cw), torch.arange(cw)], 1))
+                    off += cw
+                meta = torch.cat(meta).to(device=w.device, dtype=torch.int32).contiguous()
+            cache = (key, (w, b, meta, [m.weight.shape[0] for m in mods]))
+            self.__dict__["_text_pack"] = cache
+        return K.style_affine_all(attention_text.reshape(attention_text.shape[0], 1, -1).float(), cache[1])
+
     def _sources(self, n_codes):
         """(StyledConv, style EqualLinear, feature_map index) in concat order: attention_first on the const input
         (feature_map[-1], :796-802), then attention_c on feature_map[c] for the conv layers c < n_codes (:823-833)."""
@@ -202,15 +228,24 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
             raise RuntimeError(f"{len(src)} attention sources for an attention_last of {self.attention_last.conv.in_channel} channels")
         descs = (_AttSource * len(src))()
         keep = []  # tensors the descriptors point into
+        last = self.attention_last
+        eps = src[0][0].conv.eps
+        styles = None
+        if attention_text.is_cuda and all(sc.conv.eps == eps for sc, _, _ in src):
+            styles = self._text_styles([aff for _, aff, _ in src] + [self.attention_textca_last], attention_text)
+        demods = torch.empty((len(src), batch, 32), device=dev, dtype=torch.float32) if styles is not None else None
         for j, (sc, aff, fi) in enumerate(src):
             feat = feature_map[fi]
             feat = feat if feat.is_contiguous() else feat.contiguous()
             conv = sc.conv
             if feat.shape[1] != conv.in_channel or feat.shape[2] != feat.shape[3]:
                 raise RuntimeError(f"attention source {j}: feature {tuple(feat.shape)} for a {conv.in_channel}-channel conv")
-            style = aff(attention_text).contiguous()                                   # [B,C]  (:798, :826)
             wsc = self._wscaled_t(conv)                                                 # [C,32] = (scale*W)^T, cached
-            demod = torch.rsqrt(style.square() @ wsc.square() + conv.eps).contiguous()  # [B,32] (model.py:244-246)
+            if styles is not None:  # all 19 affines came from one launch; the 18 demodulations follow in one (below)
+                style, demod = styles[j], demods[j]
+            else:
+                style = aff(attention_text).contiguous()                               # [B,C]  (:798, :826)
+                demod = torch.rsqrt(style.square() @ wsc.square() + conv.eps).contiguous()  # [B,32] (model.py:244-246)
             nw = sc.noise.weight
             noise = None if self._noise_is_off(nw) else torch.randn(batch, size * size, device=dev)  # NoiseInjection, noise=None
             bias = sc.activate.bias.contiguous()
@@ -220,15 +255,18 @@ class FullSpaceMapperFEATClusterLinStyle_Net(nn.Module):
             d.noise = ptr(noise).value if noise is not None else None
             d.noise_w = ptr(nw).value
             d.channels, d.res = conv.in_channel, feat.shape[2]
-        last = self.attention_last
-        s_last = self.attention_textca_last(attention_text).contiguous()               # [B, 32n]
+        _lib.load()
+        if styles is not None:
+            call("w2e_attention_demod", descs, len(src), batch, float(eps), stream_ptr())
+            s_last = styles[-1]                                                         # [B, 32n]
+        else:
+            s_last = self.attention_textca_last(attention_text).contiguous()
         wl = (last.conv.weight[0, 0, :, 0, 0] * last.conv.scale).contiguous()           # [32n]
         d_last = torch.rsqrt((s_last * wl).square().sum(1) + last.conv.eps).contiguous()  # [B]
         nwl = last.noise.weight
         noise_last = None if self._noise_is_off(nwl) else torch.randn(batch, size * size, device=dev)
         partial = torch.empty((len(src), batch, size * size), device=dev, dtype=torch.float32)
         each = torch.empty((batch, size, size), device=dev, dtype=torch.float32)
-        _lib.load()
         call("w2e_attention_logits", descs, len(src), ptr(wl), ptr(s_last), ptr(d_last), ptr(last.activate.bias.contiguous()),
              ptr(noise_last), ptr(nwl), ptr(self.initial_bias), ptr(partial), ptr(each), batch, size, stream_ptr())
         del keep
