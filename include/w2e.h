@@ -121,6 +121,16 @@ int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_sc
 /* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
  *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */
 int w2e_demod_fwd(const float* s, const float* wsq, float* d, int batch, int cin, int cout, float eps, void* stream);
+/* The same for every demodulated layer of one generator pass in ONE launch (HOST array of descriptors, copied into the
+ * launch): layers[j].d[b,o] = rsqrt(sum_i s_j[b,i]^2 * wsq_j[o,i] + eps), s_j [B,cin_j], wsq_j [cout_j,cin_j], d_j [B,cout_j]. */
+#define W2E_DEMOD_MAX_LAYERS 32
+typedef struct {
+    const float* s;
+    const float* wsq;
+    float* d;
+    int cin, cout;
+} w2e_demod_layer;
+int w2e_demod_all_fwd(const w2e_demod_layer* layers, int n_layers, int batch, float eps, void* stream);
 /* gs[b,i] -= s[b,i] * sum_o dz[b,o]*d[b,o]^2*wsq[o,i]  (gs holds the direct part sum_p x*g on entry), where
  * dz[b,o] = sum_p gpre*(d*z) is either given (`dz`) or rebuilt from w2e_bias_act_bwd_reduce's `sums` as
  * s1 - noise_w*s2 - bias[o]*s3.  Exactly one of sums / dz is non-NULL.  gd (optional) receives dz/d. */

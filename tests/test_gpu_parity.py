@@ -866,3 +866,36 @@ def test_modconv_ragged_channels_never_write_past_the_output(mode, w2e_opt):
         assert_close(K.unplanar(buf[:numel].view_as(ref), w), K.unplanar(ref, w), 1e-6, mode)
     else:
         assert_close(buf[:numel].view_as(ref), ref, 2e-6 if mode == "same_split" else 1e-6, mode)
+
+
+def test_demod_coefficients_of_all_layers_in_one_launch():
+    """w2e_demod_all_fwd (every demodulated layer of a generator pass in one launch) against rsqrt(s^2 @ wsq^T + eps)
+    (model.py:241-243) in float64, on ragged layer shapes, and bit-equal to the per-layer kernel."""
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(17)
+    b = 3
+    shapes = [(512, 512), (512, 256), (72, 40), (32, 32), (64, 3)]  # (cin, cout)
+    styles = [(torch.randn(b, cin, generator=g) + 1.0).to(DEV) for cin, _ in shapes]
+    wsqs = [(torch.rand(cout, cin, generator=g) / cin).to(DEV) for cin, cout in shapes]
+    ds = K.demod_coefficients_all(styles, wsqs)
+    for s, w, d in zip(styles, wsqs, ds):
+        ref = torch.rsqrt(s.double().cpu().square() @ w.double().cpu().t() + 1e-8)
+        assert_close(d, ref, 1e-5, f"demod {tuple(w.shape)}")
+        assert torch.equal(d, K.demod_coefficients(s, w))
+
+
+def test_grad_pool_hands_out_disjoint_zeroed_regions():
+    """functional.GradPool: regions are zero, aligned, disjoint, and a request past the chunk starts a new zeroed chunk."""
+    from where2edit_amd import functional as K
+    pool = K.GradPool(1000)
+    a = pool.zeros((3, 7), DEV)
+    b_ = pool.zeros((5, 64), DEV)
+    c = pool.zeros((2000,), DEV)  # does not fit the rest of the first chunk
+    d = pool.zeros((4, 4), DEV)
+    for t in (a, b_, c, d):
+        assert t.is_contiguous() and t.data_ptr() % 256 == 0 and float(t.abs().sum()) == 0.0
+    a.fill_(1.0), b_.fill_(2.0), c.fill_(3.0), d.fill_(4.0)
+    assert float(a.sum()) == 21.0 and float(b_.sum()) == 640.0 and float(c.sum()) == 6000.0 and float(d.sum()) == 64.0
+    with K.grad_pool(16) as p:
+        assert K._GRAD_POOL is p
+    assert K._GRAD_POOL is None

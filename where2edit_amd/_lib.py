@@ -13,6 +13,10 @@ _I = ctypes.c_int
 _L = ctypes.c_int64
 _F = ctypes.c_float
 
+class DemodLayer(ctypes.Structure):  # w2e_demod_layer (include/w2e.h)
+    _fields_ = [("s", ctypes.c_void_p), ("wsq", ctypes.c_void_p), ("d", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int)]
+
+
 _PROTOS = {
     "w2e_version": (_I, []),
     "w2e_last_error": (ctypes.c_char_p, []),
@@ -31,6 +35,7 @@ _PROTOS = {
     "w2e_conv_pack": (_I, [_P, _P, _I, _I, _F, _I, _I, _P]),
     "w2e_modconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "w2e_demod_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "w2e_demod_all_fwd": (_I, [ctypes.POINTER(DemodLayer), _I, _I, _F, _P]),
     "w2e_demod_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "w2e_style_affine_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_style_affine_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -302,6 +302,31 @@ __global__ __launch_bounds__(256) void demod_fwd_kernel(const float* __restrict_
     if (lane == 0) d[row] = rsqrtf(acc + eps);
 }
 
+// The same for every demodulated layer of a generator pass in one launch (the styles of all layers are known up front when
+// the modulation affines are batched): grid (row groups of the widest layer, layer).
+struct DemodAllLaunch {
+    w2e_demod_layer layer[W2E_DEMOD_MAX_LAYERS];
+    int batch;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void demod_all_fwd_kernel(const DemodAllLaunch L) {
+    const w2e_demod_layer& y = L.layer[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= L.batch * y.cout) return;
+    const int b = row / y.cout, o = row - b * y.cout;
+    const float* s = y.s + (int64_t)b * y.cin;
+    const float* w = y.wsq + (int64_t)o * y.cin;
+    float acc = 0.f;
+    for (int i = lane; i < y.cin; i += 64) {
+        const float v = s[i];
+        acc += v * v * w[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y.d[row] = rsqrtf(acc + L.eps);
+}
+
 // Style gradient through the demodulation, added onto the direct part already in gs:
 //   dz[b,o] = sum_p gpre * (d*z)  (= s1 - nw*s2 - bias*s3 from the fused-activation reductions, or given)
 //   gd = dz / d;  dd/ds[b,i] = -d^3 * wsq[o,i] * s[b,i]   =>   gs[b,i] += -s[b,i] * sum_o dz[b,o]*d[b,o]^2*wsq[o,i]
@@ -538,6 +563,26 @@ int w2e_demod_fwd(const float* s, const float* wsq, float* d, int batch, int cin
     if (batch == 0) return 0;
     demod_fwd_kernel<<<(unsigned)ceil_div((int64_t)batch * cout, 4), 256, 0, (hipStream_t)stream>>>(s, wsq, d, batch, cin, cout, eps);
     W2E_LAUNCH_CHECK("demod_fwd");
+    return 0;
+}
+
+int w2e_demod_all_fwd(const w2e_demod_layer* layers, int n_layers, int batch, float eps, void* stream) {
+    W2E_REQUIRE(layers, "demod_all_fwd: null layers");
+    W2E_REQUIRE(n_layers >= 1 && n_layers <= W2E_DEMOD_MAX_LAYERS, "demod_all_fwd: 1 <= n_layers <= %d", W2E_DEMOD_MAX_LAYERS);
+    W2E_REQUIRE(batch >= 0, "demod_all_fwd: bad dims");
+    if (batch == 0) return 0;
+    DemodAllLaunch L{};
+    int max_cout = 0;
+    for (int j = 0; j < n_layers; ++j) {
+        W2E_REQUIRE(layers[j].s && layers[j].wsq && layers[j].d && layers[j].cin > 0 && layers[j].cout > 0,
+                    "demod_all_fwd: layer %d: null tensor or bad dims", j);
+        L.layer[j] = layers[j];
+        if (layers[j].cout > max_cout) max_cout = layers[j].cout;
+    }
+    L.batch = batch, L.eps = eps;
+    dim3 grid((unsigned)ceil_div((int64_t)batch * max_cout, 4), (unsigned)n_layers);
+    demod_all_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(L);
+    W2E_LAUNCH_CHECK("demod_all_fwd");
     return 0;
 }
 

@@ -58,10 +58,54 @@ def tail_rows(x, n):
     return _TailRows.apply(x, n)
 
 
-def _zeros_with_tail(full, n, tail_shape, device):
+class GradPool:
+    """Zeroed scratch for the [B,C]-sized gradient accumulators of ONE generator pass: its backward nodes (17 StyledConv style
+    gradients, 9 ToRGB ones, the W+ gradient) carve their buffers out of one zero-filled tensor -- one fill launch instead of 27.
+    Created per pass by `grad_pool` (the buffer itself on first use, in the backward), handed out once per region, never reused:
+    nothing is shared between steps or between graph captures."""
+
+    __slots__ = ("buf", "off", "hint")
+
+    def __init__(self, hint):
+        self.buf, self.off, self.hint = None, 0, int(hint)
+
+    def zeros(self, shape, device):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n_al = (n + 63) & ~63  # 256-byte granules: float4 / b128 accesses of the consumers stay aligned
+        if self.buf is None or self.off + n_al > self.buf.numel() or self.buf.device != torch.device(device):
+            self.buf, self.off = torch.zeros(max(n_al, self.hint), device=device, dtype=torch.float32), 0
+        out = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        return out
+
+
+_GRAD_POOL = None
+
+
+class grad_pool:
+    """`with grad_pool(hint_floats):` -- the autograd nodes created inside share one GradPool for their small zeroed gradients."""
+
+    def __init__(self, hint):
+        self.pool = GradPool(hint)
+
+    def __enter__(self):
+        global _GRAD_POOL
+        self.prev, _GRAD_POOL = _GRAD_POOL, self.pool
+        return self.pool
+
+    def __exit__(self, *exc):
+        global _GRAD_POOL
+        _GRAD_POOL = self.prev
+        return False
+
+
+def _zeros_with_tail(full, n, tail_shape, device, pool=None):
     """-> (buf, tail): a zeroed [full, *tail_shape] fp32 buffer and its rows [n:] (a contiguous view) for a kernel to write:
-    the [B,C]-sized gradients of a node inside `nograd_prefix` in one fill, no concatenation."""
-    buf = torch.zeros((full,) + tuple(tail_shape), device=device, dtype=torch.float32)
+    the [B,C]-sized gradients of a node inside `nograd_prefix` in one fill, no concatenation.  `pool`: the pass's GradPool."""
+    shape = (full,) + tuple(tail_shape)
+    buf = pool.zeros(shape, device) if pool is not None else torch.zeros(shape, device=device, dtype=torch.float32)
     return buf, (buf[n:] if n else buf)
 
 
@@ -235,6 +279,25 @@ def demod_coefficients(s, wsq, eps=1e-8):
     return d
 
 
+def demod_coefficients_all(styles, wsqs, eps=1e-8):
+    """[demod_coefficients(s, wsq) for s, wsq in zip(styles, wsqs)] in ONE launch (w2e_demod_all_fwd): the demodulation vectors of
+    every layer of a generator pass, when the styles of all layers are known up front.  styles[j]: contiguous [B,cin_j]."""
+    b = styles[0].shape[0]
+    couts = [w.shape[0] for w in wsqs]
+    buf = torch.empty(b * sum(couts), device=styles[0].device, dtype=torch.float32)
+    descs = (_lib.DemodLayer * len(styles))()
+    out, off = [], 0
+    for j, (s, w) in enumerate(zip(styles, wsqs)):
+        if s.shape != (b, w.shape[1]) or not s.is_contiguous() or not w.is_contiguous():
+            raise RuntimeError(f"demod_coefficients_all: layer {j}: style {tuple(s.shape)} for wsq {tuple(w.shape)}")
+        d = buf[off:off + b * couts[j]].view(b, couts[j])
+        off += b * couts[j]
+        descs[j].s, descs[j].wsq, descs[j].d, descs[j].cin, descs[j].cout = ptr(s).value, ptr(w).value, ptr(d).value, w.shape[1], couts[j]
+        out.append(d)
+    call("w2e_demod_all_fwd", descs, len(styles), b, float(eps), stream_ptr())
+    return out
+
+
 def unplanar(t, in_w):
     """[B,N,2,2,H+1,WP] phase-planar transposed-conv output (WP = W+1 padded to a multiple of 4) -> the plain
     [B,N,2H+1,2W+1] image."""
@@ -269,11 +332,14 @@ class _StyledConv(torch.autograd.Function):
     never optimised on this path: coach.py:174-180 optimises net.mapper only)."""
 
     @staticmethod
-    def forward(ctx, x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act, link=None):
+    def forward(ctx, x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, fuse_act, link=None, d_pre=None):
+        """`d_pre`: the layer's demodulation vector when the caller already has it (demod_coefficients_all)."""
         x, s = _c(x), _c(s)
         b, cin, h, w = x.shape
         wp_f, wp_b = packs
-        d = demod_coefficients(s, wsq) if wsq is not None else None
+        d = None
+        if wsq is not None:
+            d = d_pre if d_pre is not None else demod_coefficients(s, wsq)
         act = (noise, noise_w, bias) if fuse_act else None
         if upsample:
             t, _ = _modconv_raw(MODE_UP, x, wp_f, s, d, h, w)
@@ -289,6 +355,7 @@ class _StyledConv(torch.autograd.Function):
         ctx.cfg = (upsample, fuse_act)
         ctx.link = link  # (an ActLink shared with the consuming ToRGB node, or None)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
+        ctx.pool = _GRAD_POOL
         return out
 
     @staticmethod
@@ -308,7 +375,7 @@ class _StyledConv(torch.autograd.Function):
         # image-sized one stay unwritten (the producer node slices them off the same way), the [B,C]-sized one is zeroed
         gx_full = torch.empty((full, cin, h, w), device=x.device, dtype=torch.float32) if n_skip else None
         gx_out = gx_full[n_skip:] if n_skip else None
-        gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device)
+        gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device, ctx.pool)
         g_bias = g_nw = sums = dz = None
         blurred = False
         pre_sums = ctx.link.take(gout_full) if (fuse_act and ctx.link is not None) else None
@@ -360,11 +427,11 @@ class _StyledConv(torch.autograd.Function):
                  ptr(bias) if fuse_act else None, ptr(d), ptr(s), ptr(wsq), ptr(gs), None, b, cin, cout, stream_ptr())
         if n_skip:
             gx = gx_full
-        return gx, gs_full, None, None, g_nw, g_bias, None, None, None, None, None
+        return gx, gs_full, None, None, g_nw, g_bias, None, None, None, None, None, None
 
 
-def styled_conv(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, link=None):
-    return _StyledConv.apply(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, True, link)
+def styled_conv(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, link=None, demod=None):
+    return _StyledConv.apply(x, s, wsq, noise, noise_w, bias, packs, blur_kernel, upsample, True, link, demod)
 
 
 def modconv(x, s, wsq, packs, blur_kernel, upsample):
@@ -397,6 +464,7 @@ class _StyleAffineAll(torch.autograd.Function):
         ctx.pack = pack
         ctx.geom = (b, n_latent, dim)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
+        ctx.pool = _GRAD_POOL
         outs, off = [], 0
         for cw in widths:
             outs.append(out[off * b:(off + cw) * b].view(b, cw))
@@ -414,7 +482,7 @@ class _StyleAffineAll(torch.autograd.Function):
         parts = [(g[n_skip:].reshape(-1) if g is not None else torch.zeros(b * cw, device=w.device, dtype=torch.float32))
                  for g, cw in zip(gs, widths)]
         flat = torch.cat(parts)
-        glat_full, glat = _zeros_with_tail(b + n_skip, n_skip, (n_latent, dim), w.device)
+        glat_full, glat = _zeros_with_tail(b + n_skip, n_skip, (n_latent, dim), w.device, ctx.pool)
         call("w2e_style_affine_bwd", ptr(flat), ptr(w), ctypes.c_void_p(meta.data_ptr()), ptr(glat), b, n_latent, dim,
              w.shape[0], stream_ptr())
         return glat_full, None
@@ -455,6 +523,7 @@ class _ToRGB(torch.autograd.Function):
         ctx.link = producer_act  # (the caller vouches that this node is x's only consumer)
         ctx.has = (bias is not None, skip is not None, tuple(bias.shape) if bias is not None else None)
         ctx.n_skip = _NOGRAD_PREFIX if _NOGRAD_PREFIX < b else 0
+        ctx.pool = _GRAD_POOL
         if passthrough:
             return y, x_in.view_as(x_in)
         return y
@@ -478,7 +547,7 @@ class _ToRGB(torch.autograd.Function):
             xs, gys, gxs, accs = x, gy, gx, acc
         ws = wmod if style is not None else (wmod[n_skip:] if n_skip else wmod)
         sts = None if style is None else (style[n_skip:] if n_skip else style)
-        gw_full, gw = _zeros_with_tail(b, n_skip, (cin,) if style is not None else (3, cin), x.device)
+        gw_full, gw = _zeros_with_tail(b, n_skip, (cin,) if style is not None else (3, cin), x.device, ctx.pool)
         if ctx.link is not None:
             # x is the activated output of the StyledConv below: hand that layer its pre-activation gradient and sums directly
             sums3 = torch.empty((b - n_skip, cin, 3), device=x.device, dtype=torch.float32)

@@ -304,7 +304,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, input_is_stylespace=False):
+    def forward(self, input, style, noise=None, input_is_stylespace=False, demod=None):
         conv = self.conv
         batch = input.shape[0]
         fusable = (conv.kernel_size == 3 and not conv.downsample and noise is not None and noise.ndim == 4
@@ -323,12 +323,14 @@ class StyledConv(nn.Module):
         noise_c = noise.contiguous()
         link = K.ActLink(noise_c) if (torch.is_grad_enabled() and not conv.upsample) else None
         out = K.styled_conv(input, s2d, wsq if conv.demodulate else None, noise_c, self.noise.weight, self.activate.bias, (fwd, bwd),
-                            conv.blur.kernel if conv.upsample else None, conv.upsample, link=link)
+                            conv.blur.kernel if conv.upsample else None, conv.upsample, link=link,
+                            demod=demod if conv.demodulate else None)
         self._act_noise = link
         return out, style
 
 
 _NO_RGBPASS = bool(os.environ.get("W2E_TUNE_NO_RGBPASS"))  # tuning aid: autograd's own accumulation instead
+_NO_RGBACT = os.environ.get("W2E_TUNE_NO_RGBACT") is not None  # tuning aid: the activation backward as its own pass
 
 
 class ToRGB(nn.Module):
@@ -364,10 +366,10 @@ class ToRGB(nn.Module):
         passed = None
         if passthrough:
             out, passed = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None,
-                                   True, style=st, producer_act=producer_act if os.environ.get("W2E_TUNE_NO_RGBACT") is None else None)
+                                   True, style=st, producer_act=None if _NO_RGBACT else producer_act)
         else:
             out = K.to_rgb(input, wmod, self.bias, skip if fuse_skip else None, self.upsample.kernel if fuse_skip else None,
-                           style=st, producer_act=producer_act if os.environ.get("W2E_TUNE_NO_RGBACT") is None else None)
+                           style=st, producer_act=None if _NO_RGBACT else producer_act)
         if skip is not None and not fuse_skip:
             out = out + self.upsample(skip)
         if passthrough:
@@ -507,6 +509,15 @@ class Generator(nn.Module):
     def _synthesis(self, latent, noise, input_is_stylespace, on_layer=None, hook_layers=None):
         """`on_layer(n, is_rgb, act) -> act` is called after layer n of the plan (every layer, or only those in `hook_layers`);
         layers without a hook take the fused training forms (ToRGB pass-through, activation backward inside the ToRGB backward)."""
+        if not torch.is_grad_enabled():
+            return self._synthesis_pass(latent, noise, input_is_stylespace, on_layer, hook_layers)
+        # the [B,C]-sized gradient accumulators of this pass's backward nodes come out of one zero-filled buffer (K.GradPool)
+        batch = (latent[0] if input_is_stylespace else latent).shape[0]
+        widths = sum(m.conv.in_channel for m, _, _, _ in self._layers())
+        with K.grad_pool(batch * (3 * widths + 64 * (len(self._layers()) + 2) + self.n_latent * self.style_dim)):
+            return self._synthesis_pass(latent, noise, input_is_stylespace, on_layer, hook_layers)
+
+    def _synthesis_pass(self, latent, noise, input_is_stylespace, on_layer, hook_layers):
         hook_all = on_layer
         batch_ref = latent[0] if input_is_stylespace else latent
         out = self.input(batch_ref)
@@ -518,6 +529,11 @@ class Generator(nn.Module):
             batch = latent.shape[0]
             latent = [s.view(batch, 1, s.shape[1], 1, 1) for s in batched]
             input_is_stylespace = True
+        demods = {}
+        if batched is not None and batched[0].is_cuda:  # every layer's style is known: all demodulation vectors in one launch
+            idx = [n for n, (m, is_rgb, _, _) in enumerate(plan) if not is_rgb and m.conv.demodulate and m.conv.kernel_size == 3]
+            if idx:
+                demods = dict(zip(idx, K.demod_coefficients_all([batched[n] for n in idx], [plan[n][0].conv._derived()[2] for n in idx])))
         producer = None  # the fused-epilogue record of the StyledConv whose output `out` currently is
         for n, (mod, is_rgb, widx, nidx) in enumerate(plan):
             sty = latent[n] if input_is_stylespace else latent[:, widx]
@@ -536,7 +552,7 @@ class Generator(nn.Module):
                     skip = on_layer(n, True, skip)
                 producer = None
             else:
-                out, s = mod(out, sty, noise=noise[nidx], input_is_stylespace=input_is_stylespace)
+                out, s = mod(out, sty, noise=noise[nidx], input_is_stylespace=input_is_stylespace, demod=demods.get(n))
                 producer = getattr(mod, "_act_noise", None)
                 if on_layer is not None:
                     out = on_layer(n, False, out)
