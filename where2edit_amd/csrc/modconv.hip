@@ -304,7 +304,11 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     float4* ws = reinterpret_cast<float4*>(smem);              // [KCP/8][NTAPS][2][TN] float4
     float4* xs = reinterpret_cast<float4*>(smem + WS_FLOATS);  // [KCP/8][2][plane]     float4
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a SCALAR: everything derived from it (the wave's output-channel block, its pixel blocks, the per-register
+    // channel offsets of the epilogue's buffer stores) then lives in SGPRs -- left in a VGPR, every store's scalar-offset operand
+    // becomes a readfirstlane "waterfall" loop (64-128 of them per wave, two thirds of the kernel's instructions)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, j = lane & 31;
     const int wo = wave / WP, wpx = wave % WP;
 
@@ -703,7 +707,8 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     }
 
     // ---- epilogue
-    const float nw = (EPI == EPI_ACT && p.noise) ? p.noise_w[0] : 0.f;
+    // (EPI_ACT: the activation's gain sqrt(2) is folded into out_scale, bias and the noise strength -- lrelu(v)*g = lrelu(v*g), g > 0)
+    const float nw = (EPI == EPI_ACT && p.noise) ? p.noise_w[0] * 1.4142135623730951f : 0.f;
     float* red = smem;  // EPI_DOT: TN partial sums (reuses the weight tile after a barrier)
     if (EPI == EPI_DOT) {
         __syncthreads();
@@ -747,21 +752,34 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     unsigned yoff[NPB];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) yoff[pb] = valid[pb] ? (unsigned)pix[pb] * 4u + (unsigned)(4 * half) * plane_bytes : 0xfffffff0u;
+    // The per-channel epilogue vectors (out_scale[b,:], bias, PReLU slope) as buffer loads too: one descriptor each (N floats; a
+    // null vector = a zero-length descriptor and a uniform default), per-lane offset = the lane-half's channel, the register's
+    // channel as an immediate -- no per-lane branches.  Channels >= N read 0: their rows are never stored.  (The epilogue's
+    // instruction COUNT is what it costs: while the other waves of the SIMD stream MFMAs it issues roughly one instruction per
+    // MFMA slot, so 64-128 stores' worth of branches and address arithmetic were 40 % of a K = 32 tile's lifetime.)
+    const bool has_os = p.out_scale != nullptr, has_bs = (EPI == EPI_ACT || EPI == EPI_PRELU) && p.bias != nullptr;
+    const bool has_sl = EPI == EPI_PRELU && p.slope != nullptr;
+    const __amdgpu_buffer_rsrc_t ros = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_os ? p.out_scale + (int64_t)b * p.N : p.x), (short)0, has_os ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_bs ? p.bias : p.x), (short)0, has_bs ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_sl ? p.slope : p.x), (short)0, has_sl ? p.N * 4 : 0, 0x00020000);
+    constexpr float kGain = EPI == EPI_ACT ? 1.4142135623730951f : 1.f;
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         float os[16], bs[16];
+        const unsigned coff = (unsigned)(n0 + (wo * NOB + ob) * 32 + 4 * half) * 4u;  // the lane-half's first channel, in bytes
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            os[r] = (o < p.N && p.out_scale) ? p.out_scale[b * p.N + o] : 1.f;
-            bs[r] = ((EPI == EPI_ACT || EPI == EPI_PRELU) && o < p.N && p.bias) ? p.bias[o] : 0.f;
+            const unsigned ro = coff + (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
+            os[r] = has_os ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ros, ro, 0, 0)) * kGain : kGain;
+            bs[r] = has_bs ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbs, ro, 0, 0)) * kGain : 0.f;
         }
         float sl[EPI == EPI_PRELU ? 16 : 1];
         if (EPI == EPI_PRELU) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int o = n0 + (wo * NOB + ob) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                sl[r] = (o < p.N && p.slope) ? p.slope[o] : 1.f;
+                const unsigned ro = coff + (unsigned)((r & 3) + 8 * (r >> 2)) * 4u;
+                sl[r] = has_sl ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsl, ro, 0, 0)) : 1.f;
             }
         }
         if (EPI == EPI_DOT) {  // pass 1: loads + reductions only, 8 rows (8*NPB loads in flight per lane) at a time
@@ -807,9 +825,9 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb) {
                     float v = acc[ob][pb][r] * os[r];
-                    if (EPI == EPI_ACT) {
+                    if (EPI == EPI_ACT) {  // (os, bs, nz carry the gain)
                         v += bs[r] + nz[pb];
-                        v = (v > 0.f ? v : 0.2f * v) * 1.4142135623730951f;
+                        v = fmaxf(v, 0.2f * v);
                     }
                     if (EPI == EPI_PRELU) {
                         v += bs[r];
