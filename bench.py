@@ -10,7 +10,9 @@
 One "step" = one iteration of mapper/training/coach.py:79-92 on this rank's shard of synthetic
 FFHQ-shape W+ latents: G(w) [no grad] -> w_hat = w + 0.1 M(w) -> G(w_hat) -> CLIP loss + latent L2 ->
 backward -> (all-reduce of mapper grads) -> Ranger step.  Workload at N=1 = BASELINE configs[1]:
-FFHQ-1024 StyleGAN2 + clip_loss, batch 4.  Weak scaling: 4 latents per GPU at every N.
+FFHQ-1024 StyleGAN2 + clip_loss, batch 4.  N>1 = BASELINE configs[3]: the same step data-parallel at 8 latents per GPU
+(64 over 8 GPUs), weak scaling (8 per GPU at every N>1); the N=1 line carries `n1_b8`, the single-GPU figure at that same
+per-GPU batch, so that a 1 -> N ratio can be taken at equal per-GPU work.
 Weights are random-init of the real architectures (no network for checkpoints), data is synthetic.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -46,7 +48,7 @@ def make_opts(size, batch, workload=2):
         latent_l2_lambda=0.8, max_steps=0, description="synthetic prompt")
 
 
-def build_coach(size, batch, device, data_parallel, clip_backend, workload=2):
+def build_coach(size, batch, device, data_parallel, clip_backend="hip", workload=2):
     from where2edit_amd.clip_loss import CLIPLoss
     from where2edit_amd.clip_vit import CLIP
     from where2edit_amd.coach import Coach, synthetic_tokens
@@ -64,7 +66,7 @@ def build_coach(size, batch, device, data_parallel, clip_backend, workload=2):
             if name.endswith("noise.weight") or name.endswith("activate.bias") or name.endswith("to_rgb1.bias") \
                     or (".to_rgbs." in name and name.endswith(".bias") and p.ndim == 4):
                 p.normal_(0, 0.1)
-    clip = CLIPLoss(opts, model=CLIP(visual_backend=clip_backend))
+    clip = CLIPLoss(opts, model=CLIP())
     coach = Coach(opts, net=net, clip_loss=clip, text_inputs=synthetic_tokens(1), device=device,
                   data_parallel=data_parallel)
     return coach
@@ -202,12 +204,39 @@ def self_launch(args):
     s.close()
     procs = []
     for r in range(args.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports dmabuf IPC only; without it RCCL's intra-node
+        # transport fails in hipIpcGetMemHandle ("invalid argument").  The image exports it already -- kept (not overridden)
+        # here so that the ranks get it even from a stripped environment.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # rank 0's stdout is drained by a thread while ALL ranks are polled: a rank that dies at start-up would otherwise leave
+    # the others in init_process_group / the first all-reduce until the backend's timeout, and this parent with them
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with status {failed[1]}; the other ranks were stopped\n")
+    reader.join(timeout=10.0)
     rcs = [p.wait() for p in procs]
+    out = chunks[0] if chunks else b""
     for line in out.decode().splitlines():  # ONE JSON line on stdout (the contract); anything else rank 0 printed -> stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
@@ -254,7 +283,7 @@ def bench_config5(args, rank, world, device):
     opts = types.SimpleNamespace(stylegan_size=1024)
     g = Generator(1024, 512, 8).to(device).eval().requires_grad_(False)
     e4e = Encoder4Editing(50, "ir_se", opts).to(device).eval().requires_grad_(False)
-    clip = CLIPLoss(opts, model=CLIP(visual_backend=args.clip_backend)).to(device)
+    clip = CLIPLoss(opts, model=CLIP()).to(device)
     net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
                                                  clusters=20, cluster_dim=576).to(device).eval().requires_grad_(False)
     gen = torch.Generator().manual_seed(100 + rank)
@@ -328,9 +357,10 @@ def main():
     # measured 131 images/s as the first process on a box, 25 measured 142) and ~0.6 s timed
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=25)
-    ap.add_argument("--batch", type=int, default=4, help="latents per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="latents per GPU (weak scaling).  Default: 4 at --gpus 1 (BASELINE configs[1]), 8 at --gpus N > 1 "
+                         "(configs[3]: 64 latents over 8 GPUs)")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--clip-backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-stride", type=int, default=4,
@@ -341,6 +371,7 @@ def main():
                     help="inside the graph, fork the no-grad G(w) pass onto a second stream (+1-2 %% images/s; off by default: "
                          "overlapped kernels stretch each other's durations, so a rocprofv3 trace of the run would no longer "
                          "show the per-kernel times the roofline is quoted on)")
+    ap.add_argument("--no-n1-b8", action="store_true", help="skip the extra batch-8 measurement (`n1_b8`) of a default N=1 run")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra BASELINE configs[2] measurement of a default N=1 run")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="replay the step as one captured hipGraph (Coach.capture_step) instead of ~330 eager launches; the per-kernel "
@@ -361,6 +392,8 @@ def main():
                          "e4e encode -> cluster-pooled mask -> mapper edit -> 1024^2 generator (show_demo/try_demo.py:93-157; "
                          "replicas only at N > 1, no collective)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4 if args.gpus == 1 else 8
     tune = sorted(k for k in os.environ if k.startswith("W2E_TUNE_"))
     if tune:  # the tuning aids can skip work or force slow tiles: never measure with them set
         raise SystemExit(f"bench.py refuses to run with tuning variables set: {', '.join(tune)}")
@@ -370,7 +403,7 @@ def main():
     from where2edit_amd import _lib
     from where2edit_amd import dist as wd
     from where2edit_amd import profiling
-    rank, world, local = wd.init_from_env(backend=args.dist_backend)
+    rank, world, local = wd.init_from_env(backend=args.dist_backend, timeout_s=300)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
@@ -382,7 +415,7 @@ def main():
     _lib.set_option("conv_precision", args.conv_precision)
     if args.workload == 5:
         return bench_config5(args, rank, world, device)
-    coach = build_coach(args.size, args.batch, device, world > 1, args.clip_backend, args.workload)
+    coach = build_coach(args.size, args.batch, device, world > 1, 'hip', args.workload)
     w = synthetic_latents(coach.net.decoder, args.batch, rank)
     mask = make_mask(coach, args.batch, args.size, rank, device, args.synthetic_mask) if args.workload == 3 else None
 
@@ -454,13 +487,16 @@ def main():
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.conv_precision, "data": "synthetic",
-        "config": {"workload": (f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
+        "config": {"workload": ((f"BASELINE configs[1]: " if (world == 1 and args.batch == 4 and args.size == 1024) else
+                                 f"BASELINE configs[3] (FFHQ-1024 mapper training, global batch {global_batch}, data-parallel over {world} GPUs, "
+                                 f"RCCL all-reduce of the mapper gradients): " if (world > 1 and args.batch == 8 and args.size == 1024) else "") +
+                                f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
                                 f"LevelsMapper, Ranger, id_lambda=0") if args.workload == 2 else
                                (f"FFHQ-{args.size} mapper step with the region-attention mask (cluster-pooled, thresholded, blurred: run_attention.py:754-884"
                                 f"{' -- synthetic U(0,1) mask' if callable(mask) is False else ''}) blended at layer 13 (attention_model.py) "
                                 f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch,
-                   "parallelism": f"dp{world}", "clip_backend": args.clip_backend, "conv_precision": args.conv_precision, "final_loss": loss,
+                   "parallelism": f"dp{world}", "conv_precision": args.conv_precision, "final_loss": loss,
                    "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "mask_mean": (float(mask.last.mean()) if hasattr(mask, "last") else None), "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None},
     }
     if timer is not None:
@@ -505,13 +541,40 @@ def main():
                                  "dtype": "bf16x3", "final_loss": float(last2["loss"]),
                                  "note": "opt-in --conv-precision bf16x3: each fp32 product of the 3x3 convs as three bf16 MFMA products "
                                          "(all parity tests pass with it; DESIGN.md section 7); not the headline"}
+    if world == 1 and args.workload == 2 and args.size == 1024 and args.batch == 4 and args.conv_precision == "f32" and not args.no_n1_b8:
+        # the same step at 8 latents per GPU = the per-GPU workload of `--gpus N > 1` (BASELINE configs[3]), so that the driver's
+        # N-GPU values have a 1-GPU figure at equal per-GPU batch beside the configs[1] headline.  Never `value`.
+        del coach
+        torch.cuda.empty_cache()
+        coach8 = build_coach(args.size, 8, device, False, "hip", 2)
+        w8 = synthetic_latents(coach8.net.decoder, 8, rank)
+        step8, graph8 = (lambda: coach8.train_step(w8)), False
+        if use_graph:
+            try:
+                g8 = coach8.capture_step(w8)
+                step8, graph8 = (lambda: g8(w8)), True
+            except Exception:  # noqa: BLE001
+                torch.cuda.synchronize()
+        n8, ok8 = stabilise(step8)
+        barrier()
+        t8 = time.perf_counter()
+        for _ in range(args.steps):
+            last8 = step8()
+        barrier()
+        dt8 = time.perf_counter() - t8
+        out["n1_b8"] = {"value": 8 * args.steps / dt8, "unit": "images/s", "ms_per_step": 1e3 * dt8 / args.steps, "batch": 8,
+                        "final_loss": float(last8["loss"]), "stabilise_steps": n8, "hip_graph": graph8,
+                        "workload": "the headline step at 8 latents/GPU on 1 GPU (the per-GPU workload of BASELINE configs[3] / of "
+                                    "`bench.py --gpus N` for N > 1); same as `bench.py --batch 8`"}
+        del coach8
+        coach = None
     if world == 1 and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config3:
         # BASELINE configs[2] in the same run, so that a driver-run line exists for it: region-attention mask (the real one) +
         # clip_loss + id_loss (IR-SE50 on the conv engine), batch 8.  Reported beside the headline, never as `value`.
-        del coach
+        coach = None
         torch.cuda.empty_cache()
         b3 = 8
-        coach3 = build_coach(args.size, b3, device, False, args.clip_backend, 3)
+        coach3 = build_coach(args.size, b3, device, False, 'hip', 3)
         w3 = synthetic_latents(coach3.net.decoder, b3, rank)
         mask3 = make_mask(coach3, b3, args.size, rank, device)
         step3, graph3 = (lambda: coach3.train_step(w3, mask3)), False

@@ -45,7 +45,12 @@ const char* w2e_last_error(void);
  *                                          ordered reductions), the counterpart of the reference's
  *                                          cudnn.deterministic=True (attention/run_attention.py:903-904)
  *   "tune_cfg" [W2E_TUNE_CFG] "<cfg>[,<splits>[,<mode>]]" force a conv tile (tests, tools/layer_bench.py); "" = off
- *   "tune_upall", "tune_dma", "tune_fuse", "tune_print", "tune_blur", "tune_gemm_s": kernel-selection aids
+ *   "tune_upall", "tune_dma", "tune_fuse", "tune_print", "tune_blur", "tune_gemm_s": kernel-selection aids -- they
+ *   choose between kernels / tiles that compute the same result ("tune_blur": only bit 8, keep the LDS-tile FIR kernels
+ *   for wide images; its bits 1/2/4 and "tune_skip" / "tune_clock" drop loads, arithmetic or stores, or synchronise,
+ *   and are compiled in ONLY by -DW2E_TUNING: the shipped library ignores them)
+ *   "debug_poison" [W2E_DEBUG_POISON] "1": host-side aid -- gradient rows the merged forward declares unused are
+ *   filled with NaN instead of being left unwritten, so that a consumer that reads them fails loudly (tests)
  * w2e_get_option reads "conv_precision", "deterministic", "tune_cfg", "tuning_build" (1 = compiled with -DW2E_TUNING). */
 int w2e_set_option(const char* name, const char* value);
 int w2e_get_option(const char* name, int* value);

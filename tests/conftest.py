@@ -37,3 +37,16 @@ def w2e_opt():
     yield set_
     for name in touched:
         _lib.set_option(name, env_default.get(name, ""))
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The measured end-to-end gradient errors of this run (helpers.assert_grad_close), so that the tolerance it uses can be
+    read against what was actually observed (DESIGN.md section 2 quotes this table)."""
+    try:
+        from helpers import GRAD_ERRORS
+    except ImportError:
+        return
+    if GRAD_ERRORS:
+        terminalreporter.write_sep("-", "end-to-end gradient parity: max-norm relative error, cosine")
+        for what, e, cos in GRAD_ERRORS:
+            terminalreporter.write_line(f"{e:10.3e}  {cos:.7f}  {what}")

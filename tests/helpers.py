@@ -26,6 +26,9 @@ def assert_close(a, b, tol, what=""):
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
 
 
+GRAD_ERRORS = []  # (what, max-norm relative error, cosine) of every assert_grad_close call: printed at the end of the run (conftest)
+
+
 def assert_grad_close(a, b, what="", tol=1e-2, cos_min=0.9999):
     """Gradients THROUGH the generator: fp32 autograd of this network carries discrete noise from
     LeakyReLU kinks (a pre-activation within rounding of 0 flips its slope 0.2<->1).  Measured in the
@@ -35,4 +38,5 @@ def assert_grad_close(a, b, what="", tol=1e-2, cos_min=0.9999):
     a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
     e = rel_err(a, b)
     cos = torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)
+    GRAD_ERRORS.append((what, e, float(cos)))
     assert e <= tol and cos >= cos_min, f"{what}: grad rel err {e:.3e} (tol {tol:.0e}), cosine {cos:.6f}"

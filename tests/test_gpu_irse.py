@@ -208,8 +208,10 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
         ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
         msd["initial_state"] = torch.cat([f13[0].reshape(512, -1)[:, idx].t(), xs[:, None].repeat(1, 32), ys[:, None].repeat(1, 32)], 1)
         x = [torch.cat([text.unsqueeze(1), s[:, :, :, 0, 0]], -1) for s in codes_o]
-        new_o, mask_o, _, extra = OA.forward(msd, x, feats_o, 64, attention_text=att_text, attention_layer=att, cluster_layer=att, clusters=k,
-                                             latent_dim=edim)
+        new_o, _, _, extra = OA.forward(msd, x, feats_o, 64, attention_text=att_text, attention_layer=att, cluster_layer=att, clusters=k,
+                                        latent_dim=edim)
+        # the demo's net returns the RAW cluster-pooled map (show_demo/utils_demo.py:135-139); one threshold + one blur (:154-155)
+        mask_o = extra["same"].unsqueeze(1)
         mask_o = OA.gaussian_blur5(torch.where(mask_o < 0.8, torch.zeros_like(mask_o), mask_o))
         gen_o, _, _, _ = OG.generator_forward(gsd, [new_o], size=size, input_is_stylespace=True, randomize_noise=False, return_features=True,
                                               attention_layer=att, attention_map=mask_o, feature_map=feats_o)

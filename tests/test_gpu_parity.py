@@ -899,3 +899,29 @@ def test_grad_pool_hands_out_disjoint_zeroed_regions():
     with K.grad_pool(16) as p:
         assert K._GRAD_POOL is p
     assert K._GRAD_POOL is None
+
+
+def test_act_link_refuses_a_hooked_activation():
+    """functional.ActLink: once the ToRGB backward has applied the producing StyledConv's activation backward to the gradient
+    it returns, that gradient must reach the StyledConv backward as the very same tensor.  A tensor hook on the activation
+    replaces it on the way: the StyledConv backward must raise instead of applying the activation backward a second time."""
+    from where2edit_amd.stylegan2 import StyledConv, ToRGB
+    cin, cout, h, b = 16, 16, 16, 2
+    sc = freeze_conv_weights(StyledConv(cin, cout, 3, 512).to(DEV))
+    rgb = freeze_conv_weights(ToRGB(cout, 512, upsample=False).to(DEV))
+    x = cu(seeded.tensor("al.x", (b, cin, h, h))).requires_grad_(True)
+    w = cu(seeded.tensor("al.w", (b, 512)))
+    noise = cu(seeded.tensor("al.n", (1, 1, h, h)))
+
+    def run(hook):
+        y, _ = sc(x, w, noise=noise)
+        assert sc._act_noise is not None
+        if hook:
+            y.register_hook(lambda g: g * 1.0)
+        img, _ = rgb(y, w, producer_act=sc._act_noise)
+        return torch.autograd.grad(img.sum(), x)[0]
+
+    g_ok = run(False)
+    assert torch.isfinite(g_ok).all()
+    with pytest.raises(RuntimeError, match="ActLink"):
+        run(True)

@@ -5,28 +5,28 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r2}
+TAG=${1:-r3}
 O=$GRAFT_REPO_ROOT/gpurun_out/ev_$TAG
 R=/tmp/w2e_prof_$TAG
 rm -rf $O $R; mkdir -p $O $R
 timeout -k 10 400 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
 echo bench done
-timeout -k 10 300 python3 bench.py --workload 3 --batch 8 --no-cpu-baseline --no-preview --no-config3 > $O/bench_line_w3_b8.json 2> $O/bench_line_w3_b8.err || true
-timeout -k 10 300 python3 bench.py --workload 2 --batch 8 --no-cpu-baseline --no-preview --no-config3 > $O/bench_line_w2_b8.json 2> $O/bench_line_w2_b8.err || true
+timeout -k 10 300 python3 bench.py --workload 3 --batch 8 --no-cpu-baseline --no-preview --no-config3 --no-n1-b8 > $O/bench_line_w3_b8.json 2> $O/bench_line_w3_b8.err || true
+timeout -k 10 300 python3 bench.py --workload 2 --batch 8 --no-cpu-baseline --no-preview --no-config3 --no-n1-b8 > $O/bench_line_w2_b8.json 2> $O/bench_line_w2_b8.err || true
 echo config-3 done
 timeout -k 10 200 python3 tools/layer_bench.py --warm 1.5 --iters 50 > $O/layer_bench.txt 2>&1 || true
 timeout -k 10 200 python3 tools/mem_bench.py > $O/mem_bench.txt 2>&1 || true
 echo micro done
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats -o stats --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-preview --no-config3 --no-cpu-baseline > $O/bench_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats -o stats --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-preview --no-config3 --no-n1-b8 --no-cpu-baseline > $O/bench_stats.log 2>&1
 cp $(find $R/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats.csv auto > $O/kernel_stats_summary.txt
 echo stats done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats3 -o stats --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload 3 --batch 8 --steps 10 --warmup 3 --no-preview --no-config3 --no-cpu-baseline > $O/bench_stats_w3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/stats3 -o stats --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload 3 --batch 8 --steps 10 --warmup 3 --no-preview --no-config3 --no-n1-b8 --no-cpu-baseline > $O/bench_stats_w3.log 2>&1
 cp $(find $R/stats3 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_w3_b8.csv
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $O/kernel_stats_w3_b8.csv auto > $O/kernel_stats_w3_b8_summary.txt
 echo stats3 done
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o fetch --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-n1-b8 --no-cpu-baseline --no-kernel-timing > $O/bench_fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-n1-b8 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $(find $R/fetch -name '*counter_collection.csv' | head -1) $(find $R/write -name '*counter_collection.csv' | head -1) $TAG $O > $O/pmc.log 2>&1 || true
 echo pmc done

@@ -4,10 +4,10 @@ names (`visual.conv1.weight`, `visual.transformer.resblocks.N.attn.in_proj_weigh
 third-party package absent from the reference tree and from this image; the architecture follows the
 published `clip/model.py` (VisionTransformer, ResidualAttentionBlock, QuickGELU, LayerNorm, CLIP).
 
-fp32 throughout.  `backend="hip"` routes the visual tower's LayerNorm / QKV / attention / projection /
-MLP through the hand-written kernels of libw2e.so (include/w2e_vit.h); `backend="torch"` composes the
-same math from stock PyTorch-ROCm ops (rocBLAS GEMMs) -- used for the text tower, which runs once on
-constant tokens and is cached (coach.py:55 tokenises the description once).
+fp32 throughout.  The visual tower runs its LayerNorm / QKV / attention / projection / MLP on the hand-written
+kernels of libw2e.so (include/w2e_vit.h, vit_hip.vision_forward) and has no other execution: a CPU tensor raises.
+The text tower (`Transformer` below, stock PyTorch-ROCm ops) runs once on constant tokens and is cached (coach.py:55
+tokenises the description once).  A stock-op composition of the visual tower for A/B timing lives in tools/vit_stock.py.
 """
 import math
 from collections import OrderedDict
@@ -88,7 +88,7 @@ def patch_embed(x, weight):
 
 
 class VisionTransformer(nn.Module):
-    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, backend="hip"):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim):
         super().__init__()
         self.input_resolution, self.output_dim, self.patch_size, self.heads = input_resolution, output_dim, patch_size, heads
         self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
@@ -99,29 +99,21 @@ class VisionTransformer(nn.Module):
         self.transformer = Transformer(width, layers, heads)
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
-        self.backend = backend
 
     def forward(self, x):
-        if self.backend == "hip":
-            from . import vit_hip
-            return vit_hip.vision_forward(self, x)
-        x = patch_embed(x, self.conv1.weight)
-        b, d = x.shape[0], x.shape[2]
-        x = torch.cat([self.class_embedding.view(1, 1, d).expand(b, 1, d), x], dim=1) + self.positional_embedding
-        x = self.transformer(self.ln_pre(x))
-        return self.ln_post(x[:, 0, :]) @ self.proj
+        from . import vit_hip
+        return vit_hip.vision_forward(self, x)
 
 
 class CLIP(nn.Module):
     """ViT variants of OpenAI CLIP.  Default arguments = "ViT-B/32"."""
 
     def __init__(self, embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
-                 context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12,
-                 visual_backend="hip"):
+                 context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12):
         super().__init__()
         self.context_length = context_length
         self.visual = VisionTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
-                                        vision_width // 64, embed_dim, backend=visual_backend)
+                                        vision_width // 64, embed_dim)
         self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads, causal=True)
         self.vocab_size = vocab_size
         self.token_embedding = nn.Embedding(vocab_size, transformer_width)

@@ -186,45 +186,36 @@ class Coach:
         # that the launch-bound parts of the main branch leave idle: +1-2 % images/s); eager steps keep one stream, so that
         # per-kernel HIP-event durations are not stretched by overlap
         eager_side = self._side
-        if side_stream and self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        s_space = getattr(self.opts, "work_in_stylespace", False)
-        static_w = [c.clone() for c in w] if s_space else w.clone()
-        # a callable mask (features -> mask, e.g. the region-attention net's mask branch) is captured WITH the step: it must be
-        # stream-ordered like everything else (no host synchronisation, no .item(); the warm-up iterations below fill its caches)
-        static_mask = mask if (mask is None or callable(mask)) else mask.clone()
-        params = list(self.net.mapper.parameters())
-
-        def body():
-            if self.bucket is not None:
-                self.bucket.zero()
-            else:
-                for p in params:  # no zero fill + accumulate per parameter: the backward's own gradient tensors (static
-                    p.grad = None  # addresses in the graph's memory pool) become the .grad of every replay
-            x, x_hat, w_hat = self.forward_pair(static_w, static_mask)
-            loss, loss_dict = self.calc_loss(static_w, x, w_hat, x_hat)
-            loss.backward()
-            return loss_dict
-
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        # A captured hipMemsetAsync was observed NOT to be replayed with the graph on this ROCm stack (libw2e.so zero-fills with
-        # kernels for that reason).  torch's multi-block reductions zero their scratch with one, so a step that contains a memset
-        # (e.g. a callable mask with a large .mean()) would replay on stale scratch: refuse it here rather than diverge silently.
-        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
-            body()
-            torch.cuda.synchronize()
-        memsets = sorted({e.name for e in prof.events() if any("emset" in k.name or "fillBuffer" in k.name for k in (e.kernels or []))})
-        if memsets:
-            raise RuntimeError(f"capture_step: the step issues memset operations (from {', '.join(memsets)}); they are not replayed "
-                               "reliably inside a hipGraph here -- use an elementwise / kernel-based form (tools/graph_safety.py lists them)")
-        graph = torch.cuda.CUDAGraph()
         try:
+            if side_stream and self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            s_space = getattr(self.opts, "work_in_stylespace", False)
+            static_w = [c.clone() for c in w] if s_space else w.clone()
+            # a callable mask (features -> mask, e.g. the region-attention net's mask branch) is captured WITH the step: it must be
+            # stream-ordered like everything else (no host synchronisation, no .item(); the warm-up iterations below fill its caches)
+            static_mask = mask if (mask is None or callable(mask)) else mask.clone()
+            params = list(self.net.mapper.parameters())
+
+            def body():
+                if self.bucket is not None:
+                    self.bucket.zero()
+                else:
+                    for p in params:  # no zero fill + accumulate per parameter: the backward's own gradient tensors (static
+                        p.grad = None  # addresses in the graph's memory pool) become the .grad of every replay
+                x, x_hat, w_hat = self.forward_pair(static_w, static_mask)
+                loss, loss_dict = self.calc_loss(static_w, x, w_hat, x_hat)
+                loss.backward()
+                return loss_dict
+
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            memset_guard(body, "capture_step: the step")
+            graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = body()
         finally:
@@ -284,6 +275,25 @@ class Coach:
         """coach.py:163-172,267-272: {'state_dict': net.state_dict(), 'opts': vars(opts)}."""
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save({"state_dict": self.net.state_dict(), "opts": {k: v for k, v in vars(self.opts).items()}}, path)
+
+
+def memset_guard(body, what):
+    """A captured hipMemsetAsync was observed NOT to be replayed with the graph on this ROCm stack (libw2e.so zero-fills with
+    kernels for that reason).  torch's multi-block reductions zero their scratch with one, so a body that contains a memset
+    (e.g. a callable mask with a large .mean()) would replay on stale scratch: run it once under the profiler and refuse it here
+    rather than diverge silently.  Fails CLOSED: a profile without any device-side event (the process already runs under
+    rocprofv3, or kineto has no roctracer) proves nothing, so the capture is refused then too."""
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
+        body()
+        torch.cuda.synchronize()
+    events = prof.events()
+    if not any(e.kernels for e in events):
+        raise RuntimeError(f"{what} could not be checked for memset operations: the profiler delivered no device-side events "
+                           "(another profiler attached?) -- refusing to capture it; run eagerly (bench.py --graph off)")
+    memsets = sorted({e.name for e in events if any("emset" in k.name or "fillBuffer" in k.name for k in (e.kernels or []))})
+    if memsets:
+        raise RuntimeError(f"{what} issues memset operations (from {', '.join(memsets)}); they are not replayed "
+                           "reliably inside a hipGraph here -- use an elementwise / kernel-based form (tools/graph_safety.py lists them)")
 
 
 def synthetic_tokens(n_text=1, context_length=77, vocab_size=49408, seed=0):

@@ -14,13 +14,22 @@ namespace w2e {
 
 constexpr int MAXK = 16;
 
+// The work-skipping bits of tune_blur (1 = no global loads, 2 = no FIR arithmetic, 4 = no stores: how the kernels were
+// taken apart) exist only in a -DW2E_TUNING build; the shipped library cannot be told to skip its own work.
+// Bit 8 (keep the tile kernels for images the streaming kernel would take) selects a kernel and is always honoured.
+#ifdef W2E_TUNING
+#define W2E_BLUR_SKIP(p, bit) (((p).tune & (bit)) != 0)
+#else
+#define W2E_BLUR_SKIP(p, bit) false
+#endif
+
 struct UpfirdnParams {
     const float* x;
     const float* kern;
     float* y;
     int64_t planes;
     int in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip;
-    int tune;    // tuning aid (W2E_TUNE_BLUR): 1 = no global loads, 2 = no FIR arithmetic, 4 = no stores
+    int tune;    // tuning aid (W2E_TUNE_BLUR), -DW2E_TUNING builds only: 1 = no global loads, 2 = no FIR arithmetic, 4 = no stores
     int planar;  // 1: x is phase-planar [planes][2][2][(in_h+1)/2][(in_w+1)/2]
     int act;
     const float* out_scale;
@@ -80,13 +89,13 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
             const bool ok = iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
             // branch-free: load from a clamped (always valid) address, then select
             const int cy = iy < 0 ? 0 : (iy >= p.in_h ? p.in_h - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.in_w ? p.in_w - 1 : ix);
-            const float v = (p.tune & 1) ? 1.f : src[cy * p.in_w + cx];
+            const float v = W2E_BLUR_SKIP(p, 1) ? 1.f : src[cy * p.in_w + cx];
             if (i < PH * PW) tile[r * PITCH + c] = ok ? v : 0.f;
         }
         __syncthreads();
         float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < ((p.tune & 2) ? 1 : 5); ++r) {  // input row ly+r feeds output row 0 with ky=r and output row 1 with ky=r-1
+        for (int r = 0; r < (W2E_BLUR_SKIP(p, 2) ? 1 : 5); ++r) {  // input row ly+r feeds output row 0 with ky=r and output row 1 with ky=r-1
             const float4 a = *reinterpret_cast<const float4*>(tile + (ly + r) * PITCH + lx);
             const float4 b = *reinterpret_cast<const float4*>(tile + (ly + r) * PITCH + lx + 4);
             const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void upfirdn_tile4_kernel(UpfirdnParams p, int
                 v[j] = e;
             }
             float* dst = p.y + ((int64_t)plane * p.out_h + oy) * p.out_w + ox;
-            if ((p.tune & 4) && v[0] != 123456.75f) continue;
+            if (W2E_BLUR_SKIP(p, 4) && v[0] != 123456.75f) continue;
             if (ox + 3 < p.out_w && (p.out_w & 3) == 0) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int iy = iy0 + s_r[it];
-            const bool ok = s_mask[it] != 0 && iy >= 0 && iy < p.in_h && !(p.tune & 1);
+            const bool ok = s_mask[it] != 0 && iy >= 0 && iy < p.in_h && !W2E_BLUR_SKIP(p, 1);
             // element offset of the chunk inside the plane (all of it in the per-thread offset: never negative when ok)
             const int off = PLANAR ? ((((iy & 1) * 2 + s_par[it]) * hp + (iy >> 1)) * wpp + s_v4[it]) : (iy * p.in_w + s_v4[it]);
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)off * 4u : OOB, 0, 0));
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
         if (separable) {  // k = kv (x) kh (every StyleGAN2 blur is an outer product): 44 + 32 FMAs instead of 128
 #pragma unroll
             for (int r = 0; r < 11; ++r) {  // staged row yb+r: horizontal pass once, then it feeds output row j with ky = r - j
-                if ((p.tune & 2) && r > 0) break;
+                if (W2E_BLUR_SKIP(p, 2) && r > 0) break;
                 const float* rowp = smem + (yb + r) * PE;
                 const float hr = kh[0] * rowp[woff[0]] + kh[1] * rowp[woff[1]] + kh[2] * rowp[woff[2]] + kh[3] * rowp[woff[3]];
 #pragma unroll
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
         } else {
 #pragma unroll
             for (int r = 0; r < 11; ++r) {  // staged row yb+r feeds output row j with ky = r - j
-                if ((p.tune & 2) && r > 0) break;
+                if (W2E_BLUR_SKIP(p, 2) && r > 0) break;
                 const float* rowp = smem + (yb + r) * PE;
                 const float w0 = rowp[woff[0]], w1 = rowp[woff[1]], w2 = rowp[woff[2]], w3 = rowp[woff[3]];
 #pragma unroll
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
                 e = e * e_scale + e_bias + nw * nz[j];
                 e = (e > 0.f ? e : e * p.slope) * p.gain;
             }
-            if ((p.tune & 4) && e != 123456.75f) continue;
+            if (W2E_BLUR_SKIP(p, 4) && e != 123456.75f) continue;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, e), ry, voff0 + (unsigned)(j * p.out_w) * 4u, 0, 0);
         }
     }
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
     // (`need` false: a row nobody will consume -- the load is still ISSUED, against the empty descriptor, so that every path
     // through the loop has the same number of loads in flight and the compiler's counter waits stay partial)
     auto load_row = [&](int r, Win& w, bool need) __attribute__((always_inline)) {
-        const bool ok = need && r >= 0 && r < p.in_h && !(p.tune & 1);
+        const bool ok = need && r >= 0 && r < p.in_h && !W2E_BLUR_SKIP(p, 1);
         const __amdgpu_buffer_rsrc_t rs = ok ? rx : rzero;
         unsigned so = 0u, se = 0u;
         if (ok) {
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
     // source row r0 + k feeds output row y0 + k - a with kernel row a (a <= a_hi: rows of THIS strip); y0 % 4 == 0, so the
     // accumulator slot (k - a) & 3 is a compile-time constant at every call site (k_phase = k & 3 is passed as a literal)
     auto scatter = [&](const Win& w, const int k_phase, const int a_hi) __attribute__((always_inline)) {
-        if (p.tune & 2) return;
+        if (W2E_BLUR_SKIP(p, 2)) return;
         // taps of output pair A / B: PLANAR A = outputs (0,2): (w0,w2),(w1,w3),(w2,w4),(w3,w5) = q0,q3,q1,q4;  B = (1,3): q3,q1,q4,q2
         //                            dense  A = outputs (0,1): q0,q1,q2,q3;                                     B = (2,3): q2,q3,q4,q5
         f32x2 dq[6];
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
                 v[c] = fold ? fmaxf(e, e * p.slope) : (e > 0.f ? e : e * p.slope) * p.gain;
             }
         }
-        if ((p.tune & 4) && v[0] != 123456.75f) return;
+        if (W2E_BLUR_SKIP(p, 4) && v[0] != 123456.75f) return;
         f32x4 o;
         o[0] = v[0], o[1] = v[1], o[2] = v[2], o[3] = v[3];
         if (PLANAR || (p.out_w & 3) == 0) {  // every lane: a whole group or nothing (past the descriptor: dropped)

@@ -44,7 +44,12 @@ def invert_and_edit(images, e4e, g_ema, clip_loss, mapper, text_features, attent
     feat_orig = clip_loss.model.encode_image(clip_loss.preprocess(img_orig))
     blend_size = feats[attention_layer - 1].shape[-1]
     x = [torch.cat([text_features.unsqueeze(1), s[:, :, :, 0, 0]], dim=-1) for s in styles]
-    new_codes, mask, _ = mapper(x, feats, blend_size, attention_text=attention_text_features, strength_alpha=strength_alpha)
+    new_codes, _, _ = mapper(x, feats, blend_size, attention_text=attention_text_features, strength_alpha=strength_alpha)
+    # The demo's own copy of the net returns the RAW cluster-pooled map (show_demo/utils_demo.py:135-139: the threshold and
+    # blur lines of the training forward are commented out there) and one_text_edit thresholds and blurs it ONCE
+    # (utils_demo.py:154-155).  The training net's forward returns the thresholded + blurred map; thresholding that again
+    # would zero the blurred edges -- so the raw map is taken from the net's last forward, not from its return value.
+    mask = mapper.last["same"].unsqueeze(1)
     mask = gaussian_blur5(torch.where(mask < attention_threshold, torch.zeros_like(mask), mask))
     img_gen, _, _, _ = g_ema([new_codes], input_is_latent=True, randomize_noise=False, return_features=True, input_is_stylespace=True,
                              attention_layer=attention_layer, attention_map=mask, feature_map=feats)
@@ -70,12 +75,8 @@ def capture_invert_and_edit(images, e4e, g_ema, clip_loss, mapper, text_features
             body()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
-        body()
-        torch.cuda.synchronize()
-    memsets = sorted({e.name for e in prof.events() if any("emset" in k.name or "fillBuffer" in k.name for k in (e.kernels or []))})
-    if memsets:
-        raise RuntimeError(f"capture_invert_and_edit: the pipeline issues memset operations (from {', '.join(memsets)})")
+    from .coach import memset_guard
+    memset_guard(body, "capture_invert_and_edit: the pipeline")
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         out = body()

@@ -12,18 +12,26 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, timeout_s=None):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
-    Returns (rank, world_size, local_rank).  World size 1 needs no process group."""
+    Returns (rank, world_size, local_rank).  World size 1 needs no process group.  `timeout_s`: the process group's
+    collective timeout (a benchmark wants a rank that lost its partners to fail in minutes, not in the default 10-30)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        kw = {}
         if torch.cuda.is_available():
-            torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = local % torch.cuda.device_count()
+            torch.cuda.set_device(dev)
+            if backend == "nccl":  # bind the communicator to this rank's GPU at creation (RCCL otherwise guesses it from the
+                kw["device_id"] = torch.device("cuda", dev)  # rank at the first collective and warns)
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=timeout_s)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         # every kernel of libw2e.so launches on the CURRENT device's stream: make the rank's GPU current whatever the
         # backend and world size (gloo self-tests may map several ranks onto one GPU)

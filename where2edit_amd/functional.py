@@ -5,6 +5,7 @@ the stream (kernels are enqueued on torch's current HIP stream) and the autograd
 on image-sized tensors happens in the HIP kernels; torch ops are used only on [B,C]-sized style math.
 """
 import math
+import os
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -20,6 +21,24 @@ SQRT2 = math.sqrt(2.0)
 # gradient are batch-major, so the slices are contiguous views -- and leaves rows [:n] of the gradients it returns
 # unwritten: nothing reads them (each node's only producers / consumers are nodes that slice the same way).
 _NOGRAD_PREFIX = 0
+# Debug aid (W2E_DEBUG_POISON=1 / set_debug_poison): the prefix rows that the nodes above leave unwritten are filled with NaN,
+# so that a consumer which DOES read them (a stock op slipped between `both` and a generator node, a node that forgot to slice)
+# turns the loss / gradients into NaN instead of silently using uninitialised memory.  One fill per buffer: off by default.
+_POISON = os.environ.get("W2E_DEBUG_POISON", "0") == "1"
+
+
+def set_debug_poison(on=True):
+    global _POISON
+    _POISON = bool(on)
+
+
+def _grad_rows(shape, n_skip, device, like=None):
+    """An uninitialised full-batch gradient buffer whose rows [n_skip:] a kernel is about to write (rows [:n_skip] belong to the
+    no-grad half of a merged pass: unwritten by design, NaN under the debug option)."""
+    buf = torch.empty(shape, device=device, dtype=torch.float32) if like is None else torch.empty_like(like)
+    if _POISON and n_skip:
+        buf[:n_skip].fill_(float("nan"))
+    return buf
 
 
 class nograd_prefix:
@@ -49,7 +68,7 @@ class _TailRows(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        out = torch.empty((ctx.full,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+        out = _grad_rows((ctx.full,) + tuple(g.shape[1:]), ctx.n, g.device)
         out[ctx.n:].copy_(g)
         return out, None
 
@@ -321,7 +340,17 @@ class ActLink:
     def take(self, gout):
         gpre, sums = self.gpre, self.sums
         self.gpre = self.sums = None
-        return sums if (gpre is not None and gpre is gout) else None
+        if gpre is None:
+            return None  # the ToRGB node did not run its backward (its output was unused): the ordinary path
+        if gpre is not gout:
+            # The ToRGB backward has ALREADY applied this layer's activation backward to the gradient it returned, but what arrives
+            # here is another tensor: a hook / retain_grad on the activation, a second consumer, or an engine-side copy or
+            # accumulation changed it on the way.  Running the activation backward again would be silently wrong.
+            raise RuntimeError("where2edit_amd: the gradient of a StyledConv output that was routed through its ToRGB node "
+                               "(ActLink) reached the StyledConv backward as a different tensor -- a tensor hook, retain_grad() "
+                               "or a second consumer on that activation is not supported on the fused training path "
+                               "(use return_features=True / the unfused modules to tap activations)")
+        return sums
 
 
 class _StyledConv(torch.autograd.Function):
@@ -373,7 +402,7 @@ class _StyledConv(torch.autograd.Function):
         cout, oh, ow = out.shape[1], out.shape[2], out.shape[3]
         # inside `nograd_prefix`: full-batch gradient buffers whose tails the kernels write in place; the prefix rows of the
         # image-sized one stay unwritten (the producer node slices them off the same way), the [B,C]-sized one is zeroed
-        gx_full = torch.empty((full, cin, h, w), device=x.device, dtype=torch.float32) if n_skip else None
+        gx_full = _grad_rows((full, cin, h, w), n_skip, x.device) if n_skip else None
         gx_out = gx_full[n_skip:] if n_skip else None
         gs_full, gs_out = _zeros_with_tail(full, n_skip, (cin,), x.device, ctx.pool)
         g_bias = g_nw = sums = dz = None
@@ -538,7 +567,7 @@ class _ToRGB(torch.autograd.Function):
         if gy is None:  # only the pass-through output was used
             return gx_next, None, None, None, None, None, None, None
         gy = _c(gy)
-        gx = torch.empty_like(x)
+        gx = _grad_rows(None, n_skip, x.device, like=x)
         acc = _c(gx_next) if gx_next is not None else None
         if n_skip:  # the tails of batch-major tensors: contiguous views, written / read in place
             xs, gys, gxs = x[n_skip:], gy[n_skip:], gx[n_skip:]
@@ -563,7 +592,7 @@ class _ToRGB(torch.autograd.Function):
         gb = gys.sum((0, 2, 3)).reshape(bias_shape) if (has_bias and ctx.needs_input_grad[3]) else None
         gskip = None
         if has_skip:  # adjoint of Upsample(up=2, pad=(2,1)): down=2, un-flipped taps, leading pad 4-1-2
-            gskip = torch.empty((b, 3, h // 2, w // 2), device=x.device, dtype=torch.float32)  # rows [:n_skip]: see _StyledConv
+            gskip = _grad_rows((b, 3, h // 2, w // 2), n_skip, x.device)  # rows [:n_skip]: see _StyledConv
             _upfirdn2d_raw(gys, upk, h // 2, w // 2, 1, 2, 1, 1, False, out=gskip[n_skip:] if n_skip else gskip)
         return gx, g_wmod, g_style, gb, gskip, None, None, None
 

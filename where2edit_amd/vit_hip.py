@@ -362,7 +362,10 @@ class _TransformerV2(torch.autograd.Function):
             pbias, pres = proj_b, x_mid
             saved.append((xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h))
         out, _, _, _ = _reduce_ln(pend, pbias, pres, None, None, 0.0, want_y=False)
-        ctx.saved, ctx.blocks, ctx.wt, ctx.geom = saved, blocks, wt, (b, l, dim, heads)
+        # (through save_for_backward, not as attributes: autograd's version checks, saved-tensor hooks and its own error on a
+        # second backward without retain_graph then apply to this node as to any other)
+        ctx.save_for_backward(*[t for blk_saved in saved for t in blk_saved])
+        ctx.blocks, ctx.wt, ctx.geom = blocks, wt, (b, l, dim, heads)
         return out.reshape(b, l, dim)
 
     @staticmethod
@@ -372,7 +375,9 @@ class _TransformerV2(torch.autograd.Function):
         m = b * l
         wt = ctx.wt
         g = _c(gout).reshape(m, dim)
-        for blk, (xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h) in zip(reversed(ctx.blocks), reversed(ctx.saved)):
+        flat = ctx.saved_tensors
+        saved = [flat[8 * i:8 * i + 8] for i in range(len(ctx.blocks))]
+        for blk, (xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h) in zip(reversed(ctx.blocks), reversed(saved)):
             ln1_w, _, in_w, in_b, out_w, _, ln2_w, _, fc_w, _, proj_w, _ = _block_params(blk)
             gh = _mlp_up_grad(g, wt.get(proj_w), h)                                      # through c_proj and QuickGELU'
             gy2 = _gemm_fm(gh, wt.get(fc_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
@@ -383,7 +388,6 @@ class _TransformerV2(torch.autograd.Function):
                  stream_ptr())
             gy1 = _gemm_fm(gqkv, wt.get(in_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 3 * dim))
             g = _ln_bwd_part(gy1, xr, ln1_w, mean1, rstd1, g_mid)                        # through ln_1, + the residual branch
-        ctx.saved = None
         return g.reshape(b, l, dim), None, None, None
 
 
