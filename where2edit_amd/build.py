@@ -12,7 +12,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libw2e.so")
+# W2E_LIB_PATH: build / load another file than lib/libw2e.so (a -DW2E_TUNING diagnostic build kept beside the shipped library)
+LIB_PATH = os.environ.get("W2E_LIB_PATH") or os.path.join(LIB_DIR, "libw2e.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("W2E_HIPCC_FLAGS", "").split()  # e.g. -DW2E_STAMPS: diagnostic build with per-phase cycle stamps
@@ -35,7 +36,7 @@ def build(force=False, verbose=True):
     (git-ignored) and a translation unit is recompiled only when it, a header or the flags changed."""
     if not force and not _stale():
         return LIB_PATH
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj" if not os.environ.get("W2E_LIB_PATH") else "obj_" + os.path.basename(LIB_PATH))
     os.makedirs(obj_dir, exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
     stamp = os.path.join(obj_dir, "flags.txt")

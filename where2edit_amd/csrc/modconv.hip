@@ -55,12 +55,13 @@ struct ConvParams {
     int tiles_x, tiles_y, tiles_n;
     int ph, pw, plane;
     unsigned pw_magic;  // ceil(2^32 / pw): idx / pw == umulhi(idx, magic) for idx < 2^16
-    int border_wgs, groups_row, groups_col;  // UP: leading workgroups that compute the last row / column
+    int border_wgs, groups_row, groups_col;  // UP: leading workgroups that compute the last row / column (32-position blocks of each)
     int tune_skip;      // tuning aid (W2E_TUNE_SKIP): bit0 = no output stores, bit1 = no K loop, bit2 = stage only the first chunk, bit5 = no UP border
     const float* slope;  // EPI_PRELU: per-output-channel negative slope (v = v > 0 ? v : slope[o]*v after out_scale and bias)
     int in_off;          // DOWN: the input origin is shifted by in_off (-1 = a stride-2 convolution with padding 1 of an in_h x in_w image)
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
     unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
+    int stagger_from, stagger_to, stagger_cycles;  // workgroups [from, to) of the grid start `stagger_cycles` late (see conv_impl)
 };
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3 };
@@ -191,105 +192,122 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4
     }
 }
 
-// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the a=2
-// (row) / b=2 (column) taps reach them.  These elements are produced by the FIRST `border_wgs` workgroups of the UP
-// launch itself (same kernel, so they overlap the MFMA workgroups instead of costing a serialized launch).  One block = 8 consecutive border elements of one image x OL output
-// channels; its threads are OL channel lanes (coalesced weight reads) x KG slices of the input channels
-// (the reduction is a chain of dependent-latency loads, so it is split KG ways and unrolled), LDS-reduced.
-template <int OL, int NT>
+// Last row (Y = 2H) and last column (X = 2W) of the (2H+1)x(2W+1) transposed-conv output: only the a=2 (row) / b=2 (column)
+// taps reach them -- a 1-D transposed convolution of the last input row / column.  They are produced by the FIRST `border_wgs`
+// workgroups of the UP launch itself, on the matrix pipe: one WAVE per unit = (image, 32 output channels, 32 border positions
+// v = v0..v0+31), computing both output parities of its positions,
+//   even (X or Y = 2v):   sum_k  W[o,k,tapE0] xs[k,v] + W[o,k,tapE1] xs[k,v-1]
+//   odd  (      2v+1):    sum_k  W[o,k,tapO ] xs[k,v]
+// with xs = in_scale * x along the last row / column (0 outside it).  Both MFMA operands come straight from global memory in the
+// order the MFMA consumes them -- the packed weights hold the A operands of four consecutive MFMAs as one float4 per lane, the
+// activations are four dword loads -- with the next 8-channel group's loads in flight during the current group's 12 MFMAs; no LDS.
+// (Round 2's version did this on the VALU with one block per 8 positions x 64 channels: 1056 workgroups on the 512->256 @ 64 layer
+// at batch 8, one per CU at the kernel's LDS allocation, a latency-bound prefix of 40-190 us per up-sampling launch.)
+template <int NT>
 __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, int wg) {
-    constexpr int KG = NT / OL;
-    float (*red)[OL][8] = reinterpret_cast<float (*)[OL][8]>(smem);  // [KG][OL][8] in the kernel's dynamic LDS
-    const int groups_row = p.groups_row, groups_col = p.groups_col;
-    const int OH = 2 * p.H + 1, OW = 2 * p.W + 1;
-    const int groups = groups_row + groups_col;
-    const int n_chunks = (p.N + OL - 1) / OL;
-    const int o_chunk = wg % n_chunks, bg = wg / n_chunks;
-    const int b = bg / groups, g = bg % groups;
-    const bool is_row = g < groups_row;
-    const int e0 = (is_row ? g : g - groups_row) * 8;  // first X (row) or Y (column) of the group
-    const int lim = is_row ? OW : OH - 1;               // the corner belongs to the row
-    const int L = is_row ? p.W : p.H;                   // input extent along the border
+    constexpr int NW = NT / 64;  // the waves of a workgroup split the unit's channel range (a unit is a serial chain of dependent
+                                 // loads: its latency, not its work, is what the launch sees) and join through LDS
+    const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_ob = (p.N + 31) >> 5;
+    const int blocks = p.groups_row + p.groups_col;  // 32-position blocks of the row border, then of the column border
+    const int u = wg;                                  // one unit per workgroup
+    const int blk = u % blocks, ob = (u / blocks) % n_ob, b = u / (blocks * n_ob);
+    const bool is_row = blk < p.groups_row;
+    const int v0 = (is_row ? blk : blk - p.groups_row) * 32;
+    const int L = is_row ? p.W : p.H;  // input extent along the border
+    const int v = v0 + j;              // this lane's position (as the B operand's column and as the output column)
     const int64_t in_plane = (int64_t)p.H * p.W;
-    const int v0 = (e0 >> 1) - 1;                       // input positions v0 .. v0+4 feed 8 outputs
-    const int64_t stride = is_row ? 1 : p.W;
-    const int64_t fixed = is_row ? (int64_t)(p.H - 1) * p.W : (p.W - 1);
-    const int ol = threadIdx.x % OL, kg = threadIdx.x / OL;
-    const int o = o_chunk * OL + ol;
-    const bool ov = o < p.N;
-    // taps along the border: (2,0),(2,1),(2,2) for the row; (0,2),(1,2),(2,2) for the column
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // unconditional loads at clamped positions (masked afterwards) so that the channel loop can be batched:
-    // 4 channels = 36 independent loads in flight per thread instead of one dependent round trip per channel
-    int64_t xoff[5];
-    float msk[5];
+    // per-lane byte offsets of xs[., v] and xs[., v-1] inside one channel plane; positions outside the row / column read 0
+    const unsigned stride = is_row ? 4u : (unsigned)p.W * 4u;
+    const unsigned fixed = is_row ? (unsigned)((p.H - 1) * p.W) * 4u : (unsigned)(p.W - 1) * 4u;
+    const bool in0 = v < L, in1 = v >= 1 && v - 1 < L;
+    const unsigned off0 = fixed + (unsigned)v * stride, off1 = fixed + (unsigned)(v - 1) * stride;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (int64_t)b * p.K * in_plane), (short)0, (int)(unsigned)((int64_t)p.K * in_plane * 4), 0x00020000);
+    const int groups8 = (p.K + 7) >> 3;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), (short)0, (int)(groups8 * 9 * 2 * p.N * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in_scale ? p.in_scale + (int64_t)b * p.K : p.x), (short)0, p.in_scale ? p.K * 4 : 0, 0x00020000);
+    const bool has_is = p.in_scale != nullptr;
+    const int tapE0 = is_row ? 6 : 2, tapE1 = 8, tapO = is_row ? 7 : 5;  // (2,0),(2,2),(2,1) for the row; (0,2),(2,2),(1,2) for the column
+    const int o = ob * 32 + j;
+    const int oc = o < p.N ? o : p.N - 1;
+    const unsigned wlane = (unsigned)(half * p.N + oc) * 16u;        // float4 (tap, h, o) of a group: ((tap*2 + h)*N + o)*16 bytes
+    const unsigned wtap = 2u * (unsigned)p.N * 16u, wgroup = 9u * wtap;
+    const unsigned plane_b = (unsigned)(in_plane * 4);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x16 acc_e, acc_o;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int v = v0 + t;
-        msk[t] = (v >= 0 && v < L) ? 1.f : 0.f;
-        xoff[t] = fixed + (int64_t)(v < 0 ? 0 : (v >= L ? L - 1 : v)) * stride;
-    }
-    // The K reduction runs over 8-channel groups: the packed weights hold the 4 channels {8kc + 2c + h, c = 0..3} of one
-    // (tap, h, o) as ONE float4, so a step takes 6 float4 weight loads (the per-channel form read one float of each float4:
-    // a quarter of every line fetched) and 40 activation loads, all in flight together.
-    const int groups8 = (p.K + 7) >> 3;                            // 8-channel groups: both halves (8 channels) per step
-    const int gper = (groups8 + KG - 1) / KG;
-    const int g_lo = kg * gper, g_hi = (g_lo + gper < groups8) ? g_lo + gper : groups8;
-    const float* xb = p.x + (int64_t)b * p.K * in_plane;
-    const float4* wb4 = reinterpret_cast<const float4*>(p.wp) + (ov ? o : 0);  // packed [K/8][9][2][N] float4
-    const int64_t tap4 = 2 * (int64_t)p.N;                         // float4s per tap
-    const int64_t u0 = (is_row ? 6 : 2) * tap4, u1 = (is_row ? 7 : 5) * tap4, u2 = 8 * tap4;
-    for (int kc = g_lo; kc < g_hi; ++kc) {
-        float4 w0[2], w1[2], w2[2];
-        float xv[8][5], sv[8];
+    for (int r = 0; r < 16; ++r) acc_e[r] = 0.f, acc_o[r] = 0.f;
+    constexpr int S = 2;  // register stages: the next group's 15 loads are in flight during a group's 12 MFMAs
+    f32x4 wa[S], wb[S], wc[S];
+    float x0[S][4], x1[S][4], sc[S][4];
+    auto load = [&](int kc, int st) __attribute__((always_inline)) {
+        const unsigned wbase = (unsigned)kc * wgroup + wlane;
+        wa[st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wbase + (unsigned)tapE0 * wtap, 0, 0));
+        wb[st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wbase + (unsigned)tapE1 * wtap, 0, 0));
+        wc[st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wbase + (unsigned)tapO * wtap, 0, 0));
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {  // every load of the step is issued before the first use: one round trip per 8 channels
-            const float4* wq = wb4 + (int64_t)kc * 9 * tap4 + (int64_t)hh * p.N;
-            w0[hh] = wq[u0], w1[hh] = wq[u1], w2[hh] = wq[u2];
+        for (int c = 0; c < 4; ++c) {
+            const unsigned ch = (unsigned)(8 * kc + 2 * c + half);  // channels >= K fall past the descriptors: 0
+            // (the out-of-range marker is selected AFTER the channel offset is added: added to it, it would wrap back in range)
+            x0[st][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in0 ? off0 + ch * plane_b : 0xfffffff0u, 0, 0));
+            x1[st][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, in1 ? off1 + ch * plane_b : 0xfffffff0u, 0, 0));
+            sc[st][c] = has_is ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ch * 4u, 0, 0)) : 1.f;
+        }
+    };
+    auto fma = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int i = 8 * kc + 2 * c + hh;
-                const int ic = i < p.K ? i : p.K - 1;
-                sv[hh * 4 + c] = i < p.K ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + ic] : 1.f) : 0.f;
+        for (int c = 0; c < 4; ++c) {
+            const float a = x0[st][c] * sc[st][c], bm = x1[st][c] * sc[st][c];
+            acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[st][c], a, acc_e, 0, 0, 0);
+            acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[st][c], a, acc_o, 0, 0, 0);
+            acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[st][c], bm, acc_e, 0, 0, 0);
+        }
+    };
+    const int gper = (groups8 + NW - 1) / NW;
+    const int g_lo = wave * gper, g_hi = (g_lo + gper < groups8) ? g_lo + gper : groups8;
 #pragma unroll
-                for (int t = 0; t < 5; ++t) xv[hh * 4 + c][t] = xb[(int64_t)ic * in_plane + xoff[t]];
+    for (int st = 0; st < S; ++st)
+        if (g_lo + st < g_hi) load(g_lo + st, st);
+    for (int kc = g_lo; kc < g_hi; kc += S) {  // S groups per trip: statically indexed register stages
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (kc + st < g_hi) {
+                fma(st);
+                if (kc + st + S < g_hi) load(kc + st + S, st);
             }
         }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const float wa[4] = {w0[hh].x, w0[hh].y, w0[hh].z, w0[hh].w}, wbv[4] = {w1[hh].x, w1[hh].y, w1[hh].z, w1[hh].w},
-                        wc[4] = {w2[hh].x, w2[hh].y, w2[hh].z, w2[hh].w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float* xr = xv[hh * 4 + c];
-#pragma unroll
-                for (int t = 0; t < 5; ++t) xr[t] *= sv[hh * 4 + c] * msk[t];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {  // outputs e0+2t (even: taps 0 and 2) and e0+2t+1 (odd: tap 1)
-                    acc[2 * t] += wa[c] * xr[t + 1] + wc[c] * xr[t];
-                    acc[2 * t + 1] += wbv[c] * xr[t + 1];
-                }
-            }
-        }
     }
+    // join the NW channel slices: red[wave][reg 0..31][lane]; wave w then owns the registers [w*32/NW, (w+1)*32/NW)
+    float (*red)[32][64] = reinterpret_cast<float (*)[32][64]>(smem);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) red[kg][ol][t] = acc[t];
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc_e[r], red[wave][16 + r][lane] = acc_o[r];
     __syncthreads();
-    if (kg != 0 || !ov) return;
+    // phase-planar output [2][2][H+1][WP]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]; the row border is Y = 2H (plane row H),
+    // the column border X = 2W (plane column W); the corner (2H, 2W) belongs to the row border (v = W, even)
+    const int hp = p.H + 1, wpp = (p.W + 4) & ~3;
+    const bool even_ok = is_row ? v <= p.W : v < p.H, odd_ok = is_row ? v < p.W : v < p.H;
+    const int e_idx = is_row ? (0 * hp + p.H) * wpp + v : (0 * hp + v) * wpp + p.W;                   // (Y&1, X&1) = (0,0)
+    const int o_idx = is_row ? (1 * hp + p.H) * wpp + v : (2 * hp + v) * wpp + p.W;                   // row: (0,1); column: (1,0)
+    constexpr int RPW = 32 / NW;
 #pragma unroll
-    for (int q = 1; q < KG; ++q)
+    for (int q = 0; q < RPW; ++q) {
+        const int rr = wave * RPW + q;  // 0..15: even parity, 16..31: odd parity (uniform per wave)
+        const int r = rr & 15;
+        float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] += red[q][ol][t];
-    const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + o] : 1.f;
-    // phase-planar output [2][2][H+1][W+1]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]
-    const int hp = p.H + 1, wp = (p.W + 4) & ~3;  // 16-B aligned plane rows
-    float* yp = p.y + ((int64_t)b * p.N + o) * 4 * hp * wp;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int e = e0 + t;
-        if (e >= lim) continue;
-        const int Y = is_row ? OH - 1 : e, X = is_row ? e : OW - 1;
-        yp[(((Y & 1) * 2 + (X & 1)) * hp + (Y >> 1)) * wp + (X >> 1)] = acc[t] * os;
+        for (int w = 0; w < NW; ++w) sum += red[w][rr][lane];
+        const int och = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (och >= p.N) continue;
+        const float os = p.out_scale ? p.out_scale[(int64_t)b * p.N + och] : 1.f;
+        float* yp = p.y + ((int64_t)b * p.N + och) * 4 * hp * wpp;
+        if (rr < 16) {
+            if (even_ok) yp[e_idx] = sum * os;
+        } else if (odd_ok) {
+            yp[o_idx] = sum * os;
+        }
     }
 }
 
@@ -316,11 +334,17 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     if (is_up(MODE)) {
         if (bid < p.border_wgs) {  // uniform per workgroup
             if (W2E_SKIP(p, 32)) return;  // tuning aid: price the border workgroups
-            if (p.N >= 64) upconv_border<64, NT>(p, smem, bid);
-            else upconv_border<32, NT>(p, smem, bid);
+            upconv_border<NT>(p, smem, bid);
             return;
         }
         bid -= p.border_wgs;
+    }
+    // Stagger: the second workgroup of every CU starts late, so that the two co-resident workgroups are never in their prologue /
+    // epilogue / barrier bubbles together (workgroups dispatched later inherit the phase of the one whose slot they take).
+    if (p.stagger_cycles > 0 && (int)blockIdx.x >= p.stagger_from && (int)blockIdx.x < p.stagger_to) {
+        const unsigned long long wait = (unsigned long long)p.stagger_cycles * (unsigned)(((int)blockIdx.x - p.stagger_from) / 256 + 1);
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
     }
     // UP: phase-major grid, phase 0 (4 taps) first so the light phases fill the tail; (py,px) = (phase>>1, phase&1)
     const int per_phase = (gridDim.x - p.border_wgs) >> 2;
@@ -889,7 +913,7 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
 // The LDS-DMA pipeline is instantiated for the tiles the high-resolution layers use; other tiles keep the register pipeline.
 static bool dma_has_cfg(bool all_phase, int cfg) {
     return all_phase ? (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 11)
-                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10);
+                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12);
 }
 
 // opt-in bf16x3 form: the DOWN tile
@@ -942,6 +966,7 @@ static bool launch_mode_dma(int cfg, const ConvParams& p, int grid, size_t lds, 
             case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
             case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC, 1>(p, grid, lds, s); return true;
             case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC, 1>(p, grid, lds, s); return true;
+            case 12: launch_cfg<MODE, EPI, 2, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
         }
         return false;
     }
@@ -980,7 +1005,8 @@ static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipS
 static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},               // 512 threads, 1 workgroup / CU
                                    {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4},  // 256 threads
                                    {2, 2, 2, 4}, {2, 2, 1, 8},  // 512 threads, 4 accumulators per wave (register headroom)
-                                   {1, 8, 1, 8}};               // all-phase UP only: 32 channels x (4 phases x 2 pixel blocks)
+                                   {1, 8, 1, 8},                // all-phase UP only: 32 channels x (4 phases x 2 pixel blocks)
+                                   {2, 4, 1, 4}};               // 256 threads, 8 accumulators per wave: 64 channels x 512 pixels, two per CU (DMA, staggered)
 static const int kNumCfg = 11;  // configurations of the per-phase / SAME / DOWN kernels
 static const int kNumCfgAll = 12;
 
@@ -1024,7 +1050,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     if (batch == 0) return 0;
     {   // the kernel addresses one image's input with 32-bit byte offsets (buffer loads)
         const int64_t ih = mode == W2E_CONV_DOWN ? 2 * (int64_t)h + 1 - down_pad : h, iw = mode == W2E_CONV_DOWN ? 2 * (int64_t)w + 1 - down_pad : w;
-        W2E_REQUIRE((int64_t)k_ch * ih * iw * 4 < ((int64_t)1 << 32), "modconv3x3: one image of the input exceeds 4 GB");
+        W2E_REQUIRE(((int64_t)k_ch + (mode == W2E_CONV_UP ? 8 : 0)) * ih * iw * 4 < ((int64_t)1 << 32), "modconv3x3: one image of the input exceeds 4 GB");
         const int64_t oplane = mode == W2E_CONV_UP ? 4 * ((int64_t)h + 1) * ((w + 4) & ~3) : (int64_t)h * w;
         W2E_REQUIRE((int64_t)n_ch * oplane * 4 < ((int64_t)1 << 32) - 16 * oplane, "modconv3x3: one image of the output exceeds 4 GB");
     }
@@ -1151,7 +1177,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
 #endif
     if (opt.tune_cfg >= 0) {  // tests / tools/layer_bench.py: "<cfg>[,<splits>[,<mode>]]", third field: only launches of that mode
         const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
-        if (fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
+        if ((fc < (use_all ? kNumCfgAll : ncfg) || (fc == 12 && mode == W2E_CONV_SAME)) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
     if (opt.deterministic) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
@@ -1159,6 +1185,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const TileCfg cfg = cfgs[best];
     const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * (use_all ? cfg.npb / 4 : cfg.npb) * cfg.wp;
     p.tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
+    if (best == 12 && p.tw == 64) p.tw = 32;  // 16 x 32 pixels: the smaller patch (18 x 34) lets two workgroups' LDS stages share a CU
     p.th = tm / p.tw;
     p.tw_log2 = 0;
     while ((1 << p.tw_log2) < p.tw) ++p.tw_log2;
@@ -1177,7 +1204,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int tune_dma = opt.tune_dma;
     bool use_dma = false;
     size_t lds_dma = 0;
-    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
+    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && (best <= 2 || best == 12));
     if (!prelu && (tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
@@ -1190,7 +1217,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int kdeep_best = (up && !use_all && cfg.nob * cfg.npb < 8 && max_patch_slots(mode, tm, nt_best) <= 2) ? 16 : kc;
     size_t lds = (up && !use_all) ? sizeof(float) * ((size_t)32 * tn + (size_t)kdeep_best * p.plane)
                                   : sizeof(float) * ((size_t)kc * 9 * tn + (size_t)kc * p.plane);
-    if (up && lds < sizeof(float) * 8 * (size_t)nt_best) lds = sizeof(float) * 8 * (size_t)nt_best;  // border workgroups' reduction buffer
     bool use_x3 = false;
     if (tune_x3 == 1 && !use_dma && mode == W2E_CONV_DOWN && best == 9) {  // DOWN: not a DMA tile by default
         const int plane16 = (p.plane + 15) & ~15;
@@ -1224,10 +1250,20 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     p.k_per = (int)(ceil_div(ceil_div(k_ch, best_splits), k_gran) * k_gran);
     p.splits = (int)ceil_div(k_ch, p.k_per);
     if (up) {
-        p.groups_row = (int)ceil_div(2 * w + 1, 8), p.groups_col = (int)ceil_div(2 * h, 8);
-        p.border_wgs = batch * (p.groups_row + p.groups_col) * (int)ceil_div(n_ch, n_ch >= 64 ? 64 : 32);
+        // border units (one wave each): image x 32-channel block x 32-position block of the last row (W+1 positions) / column (H)
+        p.groups_row = (int)ceil_div(w + 1, 32), p.groups_col = (int)ceil_div(h, 32);
+        p.border_wgs = (int)((int64_t)batch * (p.groups_row + p.groups_col) * ceil_div(n_ch, 32));  // one workgroup per unit
+        if (lds < (size_t)(nt_best / 64) * 32 * 64 * sizeof(float)) lds = (size_t)(nt_best / 64) * 32 * 64 * sizeof(float);  // their join buffer
     }
     const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
+    {
+        static const int tune_stagger = getenv("W2E_TUNE_STAGGER") ? atoi(getenv("W2E_TUNE_STAGGER")) : 0;  // EXPERIMENT
+        static const int tune_stagger_r = getenv("W2E_TUNE_STAGGER_R") ? atoi(getenv("W2E_TUNE_STAGGER_R")) : 2;  // workgroups per CU
+        if (tune_stagger > 0 && nt_best == 256) {
+            p.stagger_from = p.border_wgs + 256, p.stagger_to = p.border_wgs + 256 * tune_stagger_r;
+            p.stagger_cycles = (int)((int64_t)tune_stagger * ((k_ch + 7) / 8));  // per-chunk cycles x chunks
+        }
+    }
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
 
 #ifdef W2E_TUNING
