@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define W2E_VERSION 2
+#define W2E_VERSION 3
 
 int w2e_version(void);
 const char* w2e_last_error(void);
@@ -53,6 +53,12 @@ const char* w2e_last_error(void);
  *   filled with NaN instead of being left unwritten, so that a consumer that reads them fails loudly (tests)
  * w2e_get_option reads "conv_precision", "deterministic", "tune_cfg", "tuning_build" (1 = compiled with -DW2E_TUNING). */
 int w2e_set_option(const char* name, const char* value);
+
+/* Row pitch (floats) of the phase planes of the transposed-conv output T for an input W wide: W+1 columns rounded up to 16 floats =
+ * one 64-byte memory sector, so that the 128-byte segments the conv's waves store (32 consecutive columns of a plane row) cover
+ * whole sectors and the FIR kernels' rows start on one.  (Round 2 padded to 4 floats: every segment then straddled three
+ * sectors and the T write of the 64->32 @ 512 layer ran at 2.2 TB/s, against 4.9 for the same bytes written sector-aligned.) */
+#define W2E_PLANAR_PITCH(w) ((((w) + 1) + 15) & ~15)
 int w2e_get_option(const char* name, int* value);
 
 /* ---- K2  upfirdn2d  (models/stylegan2/op/upfirdn2d.py:11-60) ---------------------------
@@ -65,7 +71,7 @@ int w2e_get_option(const char* name, int* value);
  *   y = lrelu(out_scale[p]*y + noise_w[0]*noise[oy,ox] + bias[p % channels], slope) * gain
  * enabled when act != 0; out_scale / noise / bias may be NULL (treated as 1 / 0 / 0).
  * in_layout: 0 = x is [planes, in_h, in_w]; 1 = x is the phase-planar image W2E_CONV_UP writes,
- * [planes, 2, 2, (in_h+1)/2, WP] with WP = ((in_w+1)/2 rounded up to a multiple of 4) (16-B aligned rows) and
+ * [planes, 2, 2, (in_h+1)/2, WP] with WP = W2E_PLANAR_PITCH((in_w-1)/2) (sector-aligned rows) and
  * x[Y][X] = x'[Y&1][X&1][Y>>1][X>>1]  (4x4 kernel, up=down=1 only). */
 int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, int in_h, int in_w, int out_h,
                   int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout,
@@ -110,7 +116,7 @@ int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, float scale
 
 #define W2E_CONV_SAME 0 /* stride 1, zero pad 1: [B,K,H,W] -> [B,N,H,W]              (model.py:270-274) */
 #define W2E_CONV_UP 1   /* conv_transpose stride 2, pad 0: T[B,N,2H+1,2W+1] (model.py:249-259), stored
-                         * phase-planar as [B,N,2,2,H+1,WP], WP = W+1 rounded up to a multiple of 4: T[Y][X] = y[Y&1][X&1][Y>>1][X>>1] so that every
+                         * phase-planar as [B,N,2,2,H+1,WP], WP = W2E_PLANAR_PITCH(W): T[Y][X] = y[Y&1][X&1][Y>>1][X>>1] so that every
                          * output phase is written with unit-stride, aligned rows (see w2e_upfirdn2d in_layout=1) */
 #define W2E_CONV_DOWN 2 /* stride 2, pad 0 on [B,K,2H+1,2W+1] -> [B,N,H,W] (adjoint of UP) */
 

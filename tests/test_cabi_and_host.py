@@ -41,7 +41,7 @@ def test_ctypes_prototypes_cover_the_header():
 
 
 def test_version_and_argument_errors_do_not_need_a_gpu(lib):
-    assert lib.w2e_version() == 2
+    assert lib.w2e_version() == 3
     # options: read from the environment once at load, then only through the ABI; unknown names are refused
     assert lib.w2e_set_option(b"deterministic", b"1") == 0
     v = ctypes.c_int(-1)

@@ -611,9 +611,10 @@ def test_to_rgb_passthrough_joins_gradients(cin, h, with_skip):
 
 
 def _to_planar(t, fill):
-    """[N,C,2h+1,2w+1] -> the UP conv's phase-planar [N,C,2,2,h+1,WP] (WP = w+1 padded to a multiple of 4), padding = fill."""
+    """[N,C,2h+1,2w+1] -> the UP conv's phase-planar [N,C,2,2,h+1,WP] (WP = W2E_PLANAR_PITCH(w), include/w2e.h), padding = fill."""
+    from where2edit_amd import functional as K
     n, c, ih, iw = t.shape
-    hp, wp = (ih + 1) // 2, ((iw + 1) // 2 + 3) // 4 * 4
+    hp, wp = (ih + 1) // 2, K.planar_pitch((iw - 1) // 2)
     out = torch.full((n, c, 2, 2, hp, wp), fill, device=t.device, dtype=t.dtype)
     for py in range(2):
         for px in range(2):

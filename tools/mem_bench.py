@@ -34,7 +34,7 @@ def main():
         by = 4.0 * B * c * ((2 * h + 1) ** 2 + (2 * h) ** 2)
         ms = timeit(lambda: K._upfirdn2d_raw(t, k4, 2 * h, 2 * h, 1, 1, 1, 1, True, act=(None, noise, nw, bias)))
         print(f"{'blur+act ' + str(c) + 'ch -> ' + str(2 * h):44s} {by / 1e6:8.1f} {ms:8.3f} {by / ms / 1e6:8.0f}")
-        tp = torch.randn(B, c, 2, 2, h + 1, (h + 4) // 4 * 4, device=dev)  # phase-planar T' as the UP conv writes it
+        tp = torch.randn(B, c, 2, 2, h + 1, K.planar_pitch(h), device=dev)  # phase-planar T' as the UP conv writes it
         ms = timeit(lambda: K._upfirdn2d_raw(tp, k4, 2 * h, 2 * h, 1, 1, 1, 1, True, act=(None, noise, nw, bias),
                                              planar_hw=(2 * h + 1, 2 * h + 1)))
         print(f"{'blur+act planar ' + str(c) + 'ch -> ' + str(2 * h):44s} {by / 1e6:8.1f} {ms:8.3f} {by / ms / 1e6:8.0f}")

@@ -78,7 +78,7 @@ def load():
         _ra.declare(lib)
         from . import irse_hip as _ir  # the IR-SE50 entry points (include/w2e_irse.h)
         _ir.declare(lib)
-        if lib.w2e_version() != 2:
+        if lib.w2e_version() != 3:
             raise RuntimeError("libw2e.so version mismatch: rebuild with `python -m where2edit_amd.build --force`")
         _lib = lib
     return _lib

@@ -36,7 +36,7 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ gy, const float*
                                       int64_t total) {
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const int64_t hw = (int64_t)H * W;
-    const int hp = H / 2 + 1, wp = (W / 2 + 4) & ~3;  // phase planes of T: [(H/2)+1][WP], WP = (W/2 + 1) rounded up to 4
+    const int hp = H / 2 + 1, wp = W2E_PLANAR_PITCH(W / 2);  // phase planes of T: [(H/2)+1][WP]
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
         const int64_t plane = e / hw;
         const int c = (int)(plane % C);
@@ -181,7 +181,7 @@ __global__ void shortcut_add_bwd_kernel(float* __restrict__ gx, const float* __r
                                         int64_t total) {
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const int64_t hw = (int64_t)H * W;
-    const int hp = H / 2 + 1, wp = (W / 2 + 4) & ~3;
+    const int hp = H / 2 + 1, wp = W2E_PLANAR_PITCH(W / 2);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
         const int64_t plane = e / hw;
         const int p = (int)(e - plane * hw);

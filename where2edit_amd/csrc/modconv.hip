@@ -87,6 +87,7 @@ __host__ __device__ constexpr bool is_up(int mode) { return mode == W2E_CONV_UP 
 
 // Upper bound of ceil(patch / threads) for a tile of `tm` pixels (the host refuses geometries beyond it).
 __host__ __device__ constexpr int max_patch_slots(int mode, int tm, int nt) {
+    if (nt == 1024) return mode == W2E_CONV_DOWN ? 3 : 1;  // (16-wave tiles of 512 / 256 pixels: patch <= 1024 elements)
     return mode == W2E_CONV_DOWN ? (nt == 512 ? (tm >= 1024 ? 9 : 5) : (tm >= 512 ? 9 : (tm >= 256 ? 5 : (tm >= 128 ? 3 : (tm >= 64 ? 2 : 1)))))
                                  : (nt == 512 ? (tm >= 2048 ? 5 : (tm >= 1024 ? 3 : 2)) : (tm >= 512 ? 3 : (tm >= 256 ? 2 : 1)));
 }
@@ -120,75 +121,139 @@ __device__ __forceinline__ void mul4(float4& a, const float4& s) { a.x *= s.x, a
 
 // SCALED (the LDS-DMA pipeline, where the staged activations are raw): the per-sample modulation s4[sub] = in_scale of the
 // lane-half's 4 channels is applied to the fragments after the LDS read -- to the operand with fewer fragments per chunk.
-template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX, bool SCALED, typename Hook>
+// `piece(i)` is called after the i-th accumulator group (4 MFMAs) of the chunk, i = 0 .. groups-1: the LDS-DMA pipeline issues
+// ONE piece of the next chunk's DMA there (see dma_loop).
+struct NoPiece {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int MODE, int NOB, int NPB, int KCP, int TN, int PY, int PX, bool SCALED, bool AHEAD, typename Hook, typename Piece = NoPiece>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NOB][NPB], const float4* ws, const float4* xs, int a_base,
-                                           const int (&base)[NPB], int pw, int plane, const float4 (&s4)[KCP / 8], Hook hook) {
+                                           const int (&base)[NPB], int pw, int plane, const float4 (&s4)[KCP / 8], Hook hook,
+                                           Piece piece = Piece()) {
     using T = Taps<MODE, PY, PX>;
+    // The operand fragments of tap slot i+1 are fetched BEFORE the MFMAs of slot i issue (two statically indexed register sets):
+    // the two waves of a SIMD run this code in lock-step, so an LDS round trip placed between two taps' MFMA blocks is paid by
+    // both at once, with nobody feeding the matrix pipe meanwhile -- 9 exposed latencies per chunk were the K loop's 4 %.
     if constexpr (MODE == CONV_UPALL) {
         constexpr int NPP = NPB / 4;  // pixel blocks per phase
-#pragma unroll
-        for (int sub = 0; sub < KCP / 8; ++sub) {
-            float4 bv[4][NPP];  // the 4 patch offsets (-(a>>1), -(b>>1)) the 9 taps read
+        constexpr int STEPS = (KCP / 8) * 9;
+        float4 bv[AHEAD ? 2 : 1][4][NPP];  // per 8-channel sub-chunk: the 4 patch offsets (-(a>>1), -(b>>1)) the 9 taps read
+        float4 av[AHEAD ? 2 : 1][NOB];
+        auto load_b = [&](int sub, int set) __attribute__((always_inline)) {
 #pragma unroll
             for (int off = 0; off < 4; ++off)
 #pragma unroll
-                for (int pb = 0; pb < NPP; ++pb) {
-                    bv[off][pb] = xs[base[pb] + sub * 2 * plane - (off >> 1) * pw - (off & 1)];
-                    if (SCALED) mul4(bv[off][pb], s4[sub]);
-                }
+                for (int pb = 0; pb < NPP; ++pb) bv[set][off][pb] = xs[base[pb] + sub * 2 * plane - (off >> 1) * pw - (off & 1)];
+        };
+        auto load_a = [&](int step, int set) __attribute__((always_inline)) {
 #pragma unroll
-            for (int slot = 0; slot < 9; ++slot) {
-                const int ta = slot / 3, tb = slot % 3;
-                const int phase = (ta & 1) * 2 + (tb & 1), off = (ta >> 1) * 2 + (tb >> 1);
-                float4 av[NOB];
+            for (int ob = 0; ob < NOB; ++ob) av[set][ob] = ws[a_base + step * 2 * TN + ob * 32];
+        };
+        if (AHEAD) load_b(0, 0), load_a(0, 0);
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) av[ob] = ws[a_base + (sub * 9 + slot) * 2 * TN + ob * 32];
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-                    for (int pb = 0; pb < NPP; ++pb) {
-                        f32x16& a = acc[ob][phase * NPP + pb];
-                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].x, bv[off][pb].x, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].y, bv[off][pb].y, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].z, bv[off][pb].z, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].w, bv[off][pb].w, a, 0, 0, 0);
-                    }
-                if (sub == 0 && slot == 0) hook(0);
-                if (sub == 0 && slot == 4) hook(1);
+        for (int step = 0; step < STEPS; ++step) {
+            const int sub = step / 9, slot = step % 9;
+            const int cb = AHEAD ? (sub & 1) : 0, ca = AHEAD ? (step & 1) : 0;
+            if (!AHEAD) {  // (tiles whose register budget has no room for a second fragment set)
+                if (slot == 0) load_b(sub, 0);
+                load_a(step, 0);
             }
-        }
-        return;
-    }
-    using T = Taps<MODE, PY, PX>;
-#pragma unroll
-    for (int sub = 0; sub < KCP / 8; ++sub) {
-#pragma unroll
-        for (int slot = 0; slot < T::N; ++slot) {
-            const int ta = T::ta(slot), tb = T::tb(slot);
-            float4 av[NOB], bv[NPB];
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                av[ob] = ws[a_base + (sub * T::N + slot) * 2 * TN + ob * 32];
-                if (SCALED) mul4(av[ob], s4[sub]);
+            if (AHEAD && step + 1 < STEPS) {
+                load_a(step + 1, ca ^ 1);
+                if (slot == 8) load_b(sub + 1, cb ^ 1);
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks each fetch to just in front of its first use)
             }
-            int toff;
-            if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * pw - (tb >> 1);
-            else toff = ta * pw + tb;
+            if (SCALED && slot == 0) {
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) bv[pb] = xs[base[pb] + sub * 2 * plane + toff];
+                for (int off = 0; off < 4; ++off)
+#pragma unroll
+                    for (int pb = 0; pb < NPP; ++pb) mul4(bv[cb][off][pb], s4[sub]);
+            }
+            const int ta = slot / 3, tb = slot % 3;
+            const int phase = (ta & 1) * 2 + (tb & 1), off = (ta >> 1) * 2 + (tb >> 1);
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                for (int pb = 0; pb < NPB; ++pb) {
-                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].x, bv[pb].x, acc[ob][pb], 0, 0, 0);
-                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].y, bv[pb].y, acc[ob][pb], 0, 0, 0);
-                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].z, bv[pb].z, acc[ob][pb], 0, 0, 0);
-                    acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob].w, bv[pb].w, acc[ob][pb], 0, 0, 0);
+                for (int pb = 0; pb < NPP; ++pb) {
+                    f32x16& a = acc[ob][phase * NPP + pb];
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ca][ob].x, bv[cb][off][pb].x, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ca][ob].y, bv[cb][off][pb].y, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ca][ob].z, bv[cb][off][pb].z, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ca][ob].w, bv[cb][off][pb].w, a, 0, 0, 0);
+                    piece(step * (NOB * NPP) + ob * NPP + pb);
                 }
-            if (sub == 0 && slot == 0) hook(0);
-            if (sub == 0 && slot == T::N / 2 && T::N > 1) hook(1);
-            if (sub == 0 && slot == 0 && T::N == 1) hook(1);
+            if (step == 0) hook(0);
+            if (step == 4) hook(1);
         }
+        return;
+    }
+    constexpr int STEPS = (KCP / 8) * T::N;
+    float4 av[AHEAD ? 2 : 1][NOB], bv[AHEAD ? 2 : 1][NPB];
+    auto load_one = [&](int step, int set, int piece) __attribute__((always_inline)) {  // piece < NOB: an A fragment; else a B fragment
+        const int sub = step / T::N, slot = step % T::N;
+        const int ta = T::ta(slot), tb = T::tb(slot);
+        if (piece < NOB) {
+            av[set][piece] = ws[a_base + (sub * T::N + slot) * 2 * TN + piece * 32];
+        } else {
+            int toff;
+            if (MODE == W2E_CONV_UP) toff = -(ta >> 1) * pw - (tb >> 1);
+            else toff = ta * pw + tb;
+            bv[set][piece - NOB] = xs[base[piece - NOB] + sub * 2 * plane + toff];
+        }
+    };
+    constexpr int NG = NOB * NPB, NP = NOB + NPB;  // MFMA groups (one per accumulator, 4 MFMAs each) and fragment fetches of a slot
+    if (AHEAD) {
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) load_one(0, 0, piece);
+        if (SCALED) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) mul4(av[0][ob], s4[0]);
+        }
+    }
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int sub = step / T::N, slot = step % T::N;
+        const int cur = AHEAD ? (step & 1) : 0;
+        if (!AHEAD) {  // (tiles whose register budget has no room for a second fragment set)
+#pragma unroll
+            for (int piece = 0; piece < NP; ++piece) load_one(step, 0, piece);
+            if (SCALED) {
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) mul4(av[0][ob], s4[sub]);
+            }
+        }
+        // AHEAD: the next slot's fragment fetches (NP ds_reads) and the modulation of its A fragments (NOB x 4 v_mul) are dealt out
+        // over the accumulator groups of THIS slot's MFMAs instead of standing together between two slots' MFMA blocks.  The waves of
+        // a SIMD run this stream in lock-step, so a block of non-MFMA instructions is issued by all of them at once with the matrix
+        // pipe idle meanwhile (66.8 cycles per MFMA measured in the K loop, whatever the number of waves per SIMD, with or without
+        // the chunk barriers); a single instruction between two MFMAs issues in the shadow of the partner wave's MFMA.
+        const bool more = AHEAD && step + 1 < STEPS;
+        const int nsub = (step + 1) / T::N;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                const int g = ob * NPB + pb;
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][ob].x, bv[cur][pb].x, acc[ob][pb], 0, 0, 0);
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][ob].y, bv[cur][pb].y, acc[ob][pb], 0, 0, 0);
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][ob].z, bv[cur][pb].z, acc[ob][pb], 0, 0, 0);
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][ob].w, bv[cur][pb].w, acc[ob][pb], 0, 0, 0);
+                if (more) {
+#pragma unroll
+                    for (int piece = 0; piece < NP; ++piece)  // fetch `piece` rides on group piece (NG >= NP) or floor(piece * NG / NP)
+                        if ((NG >= NP ? piece : (piece * NG) / NP) == g) load_one(step + 1, cur ^ 1, piece);
+                    if (SCALED) {
+#pragma unroll
+                        for (int o2 = 0; o2 < NOB; ++o2)  // the modulation of A fragment o2 on one of the last NOB groups (after its fetch)
+                            if (g == NG - NOB + o2) mul4(av[cur ^ 1][o2], s4[nsub]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                piece(step * NG + g);
+            }
+        if (sub == 0 && slot == 0) hook(0);
+        if (sub == 0 && slot == T::N / 2 && T::N > 1) hook(1);
+        if (sub == 0 && slot == 0 && T::N == 1) hook(1);
     }
 }
 
@@ -287,7 +352,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
     __syncthreads();
     // phase-planar output [2][2][H+1][WP]: element (Y,X) lives at [Y&1][X&1][Y>>1][X>>1]; the row border is Y = 2H (plane row H),
     // the column border X = 2W (plane column W); the corner (2H, 2W) belongs to the row border (v = W, even)
-    const int hp = p.H + 1, wpp = (p.W + 4) & ~3;
+    const int hp = p.H + 1, wpp = W2E_PLANAR_PITCH(p.W);
     const bool even_ok = is_row ? v <= p.W : v < p.H, odd_ok = is_row ? v < p.W : v < p.H;
     const int e_idx = is_row ? (0 * hp + p.H) * wpp + v : (0 * hp + v) * wpp + p.W;                   // (Y&1, X&1) = (0,0)
     const int o_idx = is_row ? (1 * hp + p.H) * wpp + v : (2 * hp + v) * wpp + p.W;                   // row: (0,1); column: (1,0)
@@ -312,7 +377,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
 }
 
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, int DMA>
-__global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WO * WP, (64 * WO * WP == 1024 ? 4 : 2)) void modconv_kernel(ConvParams p) {
     constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
     constexpr int TN = 32 * NOB * WO;
     constexpr int NPX = (MODE == CONV_UPALL) ? NPB / 4 : NPB;  // pixel blocks per wave (UPALL: NPB = 4 phases x NPX)
@@ -501,9 +566,9 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
             // the next chunk's loads are issued from inside the MFMA stream; the two waves that share a SIMD (w, w+4 in a
             // 512-thread workgroup) do it at different taps so that one of them always feeds the matrix pipe
             const bool do_pf = k0 + KCP < k_hi && !W2E_SKIP(p, 4);
-            const int my_pos = (NT == 512) ? (wave >> 2) : 0;
+            const int my_pos = (NT >= 512) ? ((wave >> 2) & 1) : 0;
             const float4 no_scale[KCP / 8] = {};
-            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX, false>(acc, ws, xs, a_base, base, p.pw, p.plane, no_scale, [&](int pos) __attribute__((always_inline)) {
+            mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX, false, false>(acc, ws, xs, a_base, base, p.pw, p.plane, no_scale, [&](int pos) __attribute__((always_inline)) {
                 if (do_pf && pos == my_pos) prefetch(k0 + KCP);
             });
         }
@@ -535,10 +600,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         float* const stw = smem + (DMA == 2 ? stage_floats + 4 * (20 * TN + 2 * p.plane) : 2 * stage_floats);
         const float4* const st = reinterpret_cast<const float4*>(stw);
         const int a_base = half * TN + wo * NOB * 32 + j;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.x + (int64_t)b * p.K * in_plane), (short)0, (int)(unsigned)((int64_t)p.K * in_plane * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.wp), (short)0, (int)(((p.K + 7) >> 3) * 9 * 2 * p.N * 16), 0x00020000);
         unsigned xoff[XT], woff[WQ];
         const unsigned cplane = (unsigned)(2 * (lane & 3)) * (unsigned)(in_plane * 4);
 #pragma unroll
@@ -560,33 +621,74 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
             const int oc = n0 + o < p.N ? n0 + o : p.N - 1;
             woff[t] = q < WQ4 ? (unsigned)sub * wgroup_bytes + (unsigned)(((tap * 2 + hh) * p.N + oc) * 16) : 0xfffffff0u;
         }
+        // The DMA goes out through inline assembly, not __builtin_amdgcn_raw_ptr_buffer_load_lds: for the builtin the compiler knows
+        // an asynchronous LDS write is in flight and, lacking alias information, puts `s_waitcnt vmcnt(0)` in front of the next
+        // ds_read -- the issuing wave then sat out the whole flight time of its pieces (2-5 k cycles per chunk, read off the ISA and
+        // off the stamps: "DMA issue" 14 % of a SAME tile's K loop, 26 % of an all-phase UP tile's) right after issuing them.  The
+        // only wait the pipeline needs is the vmcnt(0) in front of the barrier that opens the NEXT chunk.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto raw_rsrc = [](const float* ptr, unsigned bytes) __attribute__((always_inline)) {  // base, stride 0, size, raw-buffer flags
+            const uint64_t a64 = (uint64_t)(uintptr_t)ptr;
+            i32x4 d;
+            d[0] = (int)(unsigned)a64, d[1] = (int)(unsigned)((a64 >> 32) & 0xffffu), d[2] = (int)bytes, d[3] = 0x00020000;
+            return d;
+        };
+        const i32x4 qx = raw_rsrc(p.x + (int64_t)b * p.K * in_plane, (unsigned)((int64_t)p.K * in_plane * 4));
+        const i32x4 qw = raw_rsrc(p.wp, (unsigned)(((p.K + 7) >> 3) * 9 * 2 * p.N * 16));
+        const unsigned lds0 = (unsigned)(uintptr_t)l0;
+        // One piece (one wave-instruction) of a chunk's DMA: pieces 0 .. WQ-1 are the weights, then the (sub, h) planes of the patch.
+        // Issued back to back, a wave's 15-17 pieces took it 5-6 k cycles (the CU's texture path accepts one such instruction per
+        // ~90 cycles, and all waves queue on it at once) during which it fed the matrix pipe nothing; dealt out one per few MFMA
+        // groups over the whole chunk (mfma_chunk's `piece`), each finds the path free.
+        constexpr int NPIECE = WQ + 2 * (KC / 8) * XT;
+        auto issue_piece = [&](int k0, int stage, int i) __attribute__((always_inline)) {
+            const unsigned lb = lds0 + (unsigned)(stage * stage_floats * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (i < WQ) {
+                const int t = i;
+                const int start = t * NT + swave * 64;
+                const unsigned wbase = (unsigned)(k0 >> 3) * wgroup_bytes;
+                if ((t + 1) * NT <= WQ4 || start < WQ4)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lb + (unsigned)(start * 16)), "v"(woff[t]), "s"(qw), "s"(wbase) : "memory");
+            } else if (i < NPIECE) {
+                const int sh = (i - WQ) / XT, t = (i - WQ) % XT;
+                const unsigned soff = (unsigned)(k0 + (sh >> 1) * 8 + (sh & 1)) * (unsigned)(in_plane * 4);
+                const unsigned xb = lb + (unsigned)((WS_FLOATS + sh * plane4) * 4);
+                const int start = t * NT + swave * 64;
+                if (t < XT_MIN || start < plane4)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(xb + (unsigned)(start * 4)), "v"(xoff[t]), "s"(qx), "s"(soff) : "memory");
+            }
+#endif
+        };
         auto issue = [&](int k0, int stage) __attribute__((always_inline)) {
-            lds_char* const lb = l0 + stage * stage_floats * 4;
+            const unsigned lb = lds0 + (unsigned)(stage * stage_floats * 4);
             const unsigned wbase = (unsigned)(k0 >> 3) * wgroup_bytes;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
             for (int t = 0; t < WQ; ++t) {
                 const int start = t * NT + swave * 64;
-#if defined(__HIP_DEVICE_COMPILE__)  // (hipcc's host pass rejects the 16-byte form silently and then drops the kernel's host stub)
-                if ((t + 1) * NT <= WQ4 || start < WQ4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lb + start * 16), 16, woff[t], wbase, 0, 0);
-#endif
+                if ((t + 1) * NT <= WQ4 || start < WQ4)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lb + (unsigned)(start * 16)), "v"(woff[t]), "s"(qw), "s"(wbase) : "memory");
             }
 #pragma unroll
             for (int sh = 0; sh < 2 * (KC / 8); ++sh) {  // the (sub, h) planes of the patch
                 const unsigned soff = (unsigned)(k0 + (sh >> 1) * 8 + (sh & 1)) * (unsigned)(in_plane * 4);
-                lds_char* const xb = lb + (WS_FLOATS + sh * plane4) * 4;
+                const unsigned xb = lb + (unsigned)((WS_FLOATS + sh * plane4) * 4);
 #pragma unroll
                 for (int t = 0; t < XT; ++t) {
                     const int start = t * NT + swave * 64;
-                    if (t < XT_MIN || start < plane4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(xb + start * 4), 4, xoff[t], soff, 0, 0);
+                    if (t < XT_MIN || start < plane4)
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(xb + (unsigned)(start * 4)), "v"(xoff[t]), "s"(qx), "s"(soff) : "memory");
                 }
             }
+#endif
         };
         if (k_lo < k_hi) issue(k_lo, 0);
         for (int e = tid; e < ((p.K + 7) >> 3) * 8; e += NT) {
             const int ch = 8 * (e >> 3) + 2 * (e & 3) + ((e >> 2) & 1);
             stw[e] = ch < p.K ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + ch] : 1.f) : 0.f;
         }
-        const int my_pos = (NT == 512) ? (swave >> 2) : 0;
+        const int my_pos = (NT >= 512) ? ((swave >> 2) & 1) : 0;
         if constexpr (DMA == 2) {
             // ---- opt-in (W2E_CONV_PRECISION=bf16x3): fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16.  The chunk lands by
             // LDS-DMA in the fp32 layout (staging area S), is split into hi = bf16(a), lo = bf16(a - hi) while it is copied
@@ -684,26 +786,37 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
             const unsigned long long tc = __builtin_amdgcn_s_memtime();
             st_wait += tb - ta, st_bar += tc - tb;
 #else
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of chunk k0 have landed ...
-            __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
+            if (!W2E_SKIP(p, 8) || k0 == k_lo) {  // (tuning aid, bit 3: no wait / barrier after the first chunk)
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of chunk k0 have landed ...
+                __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
+            }
 #endif
             const float4* wsc = reinterpret_cast<const float4*>(smem + stage * stage_floats);
             const float4* xsc = wsc + WS_FLOATS / 4;
             float4 s4[KC / 8];
 #pragma unroll
             for (int sub = 0; sub < KC / 8; ++sub) s4[sub] = st[((k0 >> 3) + sub) * 2 + half];
-            const bool do_pf = k0 + KC < k_hi;
-            mfma_chunk<MODE, NOB, NPB, KC, TN, 0, 0, true>(acc, wsc, xsc, a_base, base, p.pw, p.plane, s4, [&](int pos) __attribute__((always_inline)) {
+            const bool do_pf = k0 + KC < k_hi && !W2E_SKIP(p, 4);  // (tuning aid, bit 2: stage only the first chunk)
+            // groups of this chunk: (KC/8) x 9 taps x accumulators per tap (all-phase UP: a tap feeds one phase's accumulators)
+            constexpr int GROUPS = (KC / 8) * 9 * (MODE == CONV_UPALL ? NOB * (NPB / 4) : NOB * NPB);
+            constexpr int PSTRIDE = GROUPS / NPIECE > 0 ? GROUPS / NPIECE : 1;             // a piece every PSTRIDE groups, or
+            constexpr int PPG = NPIECE <= GROUPS ? 1 : (NPIECE + GROUPS - 1) / GROUPS;   // PPG pieces per group (most of them empty slots)
+            mfma_chunk<MODE, NOB, NPB, KC, TN, 0, 0, true, (NT == 512 || (NT == 256 && NOB * NPB >= 8))>(
+                acc, wsc, xsc, a_base, base, p.pw, p.plane, s4, [&](int) __attribute__((always_inline)) {},
+                [&](int g) __attribute__((always_inline)) {
+                    if (g % PSTRIDE == 0 && (g / PSTRIDE) * PPG < NPIECE) {
 #ifdef W2E_STAMPS
-                if (do_pf && pos == my_pos) {
-                    const unsigned long long ti = __builtin_amdgcn_s_memtime();
-                    issue(k0 + KC, stage ^ 1);
-                    st_issue += __builtin_amdgcn_s_memtime() - ti;
-                }
-#else
-                if (do_pf && pos == my_pos) issue(k0 + KC, stage ^ 1);
+                        const unsigned long long ti = __builtin_amdgcn_s_memtime();
 #endif
-            });
+                        if (do_pf) {
+#pragma unroll
+                            for (int q = 0; q < PPG; ++q) issue_piece(k0 + KC, stage ^ 1, (g / PSTRIDE) * PPG + q);
+                        }
+#ifdef W2E_STAMPS
+                        st_issue += __builtin_amdgcn_s_memtime() - ti;
+#endif
+                    }
+                });
         }
 #ifdef W2E_STAMPS
         if (p.stamps && tid == 0) {
@@ -758,11 +871,11 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
     for (int pb = 0; pb < NPB; ++pb) {
         // UP writes its phase plane of the phase-planar image [4][H+1][W+1]: unit-stride rows
         const int ph_pb = (MODE == CONV_UPALL) ? pb / NPX : phase;
-        if (is_up(MODE)) pix[pb] = (ph_pb * (p.H + 1) + gy[pb]) * ((p.W + 4) & ~3) + gx[pb];
+        if (is_up(MODE)) pix[pb] = (ph_pb * (p.H + 1) + gy[pb]) * W2E_PLANAR_PITCH(p.W) + gx[pb];
         else pix[pb] = gy[pb] * p.out_w + gx[pb];
         nz[pb] = (EPI == EPI_ACT && p.noise && valid[pb]) ? nw * p.noise[gy[pb] * p.out_w + gx[pb]] : 0.f;
     }
-    const int out_plane = is_up(MODE) ? 4 * (p.H + 1) * ((p.W + 4) & ~3) : p.out_h * p.out_w;
+    const int out_plane = is_up(MODE) ? 4 * (p.H + 1) * W2E_PLANAR_PITCH(p.W) : p.out_h * p.out_w;
     // Output (and dot_with) accesses as buffer operations on a descriptor spanning this image's N planes: per-lane byte
     // offset (pixel, + 4 planes for the upper lane-half) computed once, per-register scalar offset = the output channel's
     // plane.  Pixels outside the tile/image carry an out-of-range offset; channels >= N fall past the descriptor: the
@@ -913,7 +1026,7 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
 // The LDS-DMA pipeline is instantiated for the tiles the high-resolution layers use; other tiles keep the register pipeline.
 static bool dma_has_cfg(bool all_phase, int cfg) {
     return all_phase ? (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 11)
-                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12);
+                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14);
 }
 
 // opt-in bf16x3 form: the DOWN tile
@@ -967,6 +1080,8 @@ static bool launch_mode_dma(int cfg, const ConvParams& p, int grid, size_t lds, 
             case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC, 1>(p, grid, lds, s); return true;
             case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC, 1>(p, grid, lds, s); return true;
             case 12: launch_cfg<MODE, EPI, 2, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
+            case 13: launch_cfg<MODE, EPI, 2, 2, 2, 8, KC, 1>(p, grid, lds, s); return true;
+            case 14: launch_cfg<MODE, EPI, 2, 2, 1, 16, KC, 1>(p, grid, lds, s); return true;
         }
         return false;
     }
@@ -1006,7 +1121,9 @@ static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},     
                                    {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4},  // 256 threads
                                    {2, 2, 2, 4}, {2, 2, 1, 8},  // 512 threads, 4 accumulators per wave (register headroom)
                                    {1, 8, 1, 8},                // all-phase UP only: 32 channels x (4 phases x 2 pixel blocks)
-                                   {2, 4, 1, 4}};               // 256 threads, 8 accumulators per wave: 64 channels x 512 pixels, two per CU (DMA, staggered)
+                                   {2, 4, 1, 4},                // 256 threads, 8 accumulators per wave: 64 channels x 512 pixels, two per CU (DMA, staggered)
+                                   {2, 2, 2, 8},                // 1024 threads, 4 accumulators per wave: cfg 0's 128 x 512 tile on 16 waves (4 per SIMD)
+                                   {2, 2, 1, 16}};              // 1024 threads: cfg 1's 64 x 1024 tile on 16 waves
 static const int kNumCfg = 11;  // configurations of the per-phase / SAME / DOWN kernels
 static const int kNumCfgAll = 12;
 
@@ -1051,7 +1168,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     {   // the kernel addresses one image's input with 32-bit byte offsets (buffer loads)
         const int64_t ih = mode == W2E_CONV_DOWN ? 2 * (int64_t)h + 1 - down_pad : h, iw = mode == W2E_CONV_DOWN ? 2 * (int64_t)w + 1 - down_pad : w;
         W2E_REQUIRE(((int64_t)k_ch + (mode == W2E_CONV_UP ? 8 : 0)) * ih * iw * 4 < ((int64_t)1 << 32), "modconv3x3: one image of the input exceeds 4 GB");
-        const int64_t oplane = mode == W2E_CONV_UP ? 4 * ((int64_t)h + 1) * ((w + 4) & ~3) : (int64_t)h * w;
+        const int64_t oplane = mode == W2E_CONV_UP ? 4 * ((int64_t)h + 1) * W2E_PLANAR_PITCH(w) : (int64_t)h * w;
         W2E_REQUIRE((int64_t)n_ch * oplane * 4 < ((int64_t)1 << 32) - 16 * oplane, "modconv3x3: one image of the output exceeds 4 GB");
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1177,7 +1294,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
 #endif
     if (opt.tune_cfg >= 0) {  // tests / tools/layer_bench.py: "<cfg>[,<splits>[,<mode>]]", third field: only launches of that mode
         const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
-        if ((fc < (use_all ? kNumCfgAll : ncfg) || (fc == 12 && mode == W2E_CONV_SAME)) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
+        if ((fc < (use_all ? kNumCfgAll : ncfg) || (fc >= 12 && fc <= 14 && mode == W2E_CONV_SAME)) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
     if (opt.deterministic) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
@@ -1204,7 +1321,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int tune_dma = opt.tune_dma;
     bool use_dma = false;
     size_t lds_dma = 0;
-    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && (best <= 2 || best == 12));
+    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && (best <= 2 || best >= 12));
     if (!prelu && (tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
@@ -1283,7 +1400,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     }
 #endif
     if (p.splits > 1 &&
-        zero_async(y, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * ((w + 4) & ~3) : p.out_h * p.out_w), s) != hipSuccess) {
+        zero_async(y, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * W2E_PLANAR_PITCH(w) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
         return 2;
     }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpfirdnParams p, int
         for (int i = 0; i < 16; ++i) separable = separable && fabsf(kr[i] - kv[i >> 2] * kh[i & 3]) <= 1e-7f * kmax;
     }
     const float nw = (ACT && p.noise) ? p.noise_w[0] : 0.f;
-    const int hp = (p.in_h + 1) >> 1, wpp = (((p.in_w + 1) >> 1) + 3) & ~3;
+    const int hp = (p.in_h + 1) >> 1, wpp = W2E_PLANAR_PITCH((p.in_w - 1) >> 1);  // (in_w = 2W+1)
     const int64_t plane_stride = PLANAR ? (int64_t)4 * hp * wpp : (int64_t)p.in_h * p.in_w;
     const int row_len = PLANAR ? wpp : p.in_w;                       // floats per source row (a multiple of 4)
 
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void upfirdn_stream4_kernel(UpfirdnParams p, i
     }
 
     // ---- source addressing.  Window columns: w_i = source column ox - pad_x0 + i, i = 0..6 (7 = 0).
-    const int hp = (p.in_h + 1) >> 1, wpp = (((p.in_w + 1) >> 1) + 3) & ~3;
+    const int hp = (p.in_h + 1) >> 1, wpp = W2E_PLANAR_PITCH((p.in_w - 1) >> 1);  // (in_w = 2W+1)
     const int64_t plane_stride = PLANAR ? (int64_t)4 * hp * wpp : (int64_t)p.in_h * p.in_w;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)plane * plane_stride), (short)0,
                                                                         (int)(plane_stride * 4), 0x00020000);

@@ -139,6 +139,9 @@ def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=
     `out`: a contiguous [n,c,out_h,out_w] tensor to write (e.g. the tail rows of a larger batch) instead of allocating."""
     n, c = x.shape[0], x.shape[1]
     h, w = planar_hw if planar_hw is not None else (x.shape[2], x.shape[3])
+    if planar_hw is not None and tuple(x.shape[2:]) != (2, 2, (h + 1) // 2, planar_pitch((w - 1) // 2)):
+        raise RuntimeError(f"upfirdn2d: a phase-planar input of a {h}x{w} image must be [N,C,2,2,{(h + 1) // 2},{planar_pitch((w - 1) // 2)}] "
+                           f"(W2E_PLANAR_PITCH, include/w2e.h), got {tuple(x.shape)}")
     kh, kw = kernel.shape
     y = out if out is not None else torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32)
     if act is None:
@@ -251,7 +254,7 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     if wp.shape[0] != (k + 7) // 8:
         raise RuntimeError(f"modconv: packed weight holds {wp.shape[0]} 8-channel groups, input has {k} channels")
     if mode == MODE_UP:  # phase-planar T: T[Y][X] = y[Y&1][X&1][Y>>1][X>>1]  (unit-stride stores per output phase)
-        y = torch.empty((b, n, 2, 2, h + 1, (w + 4) & ~3), device=x.device, dtype=torch.float32)  # 16-B aligned rows
+        y = torch.empty((b, n, 2, 2, h + 1, planar_pitch(w)), device=x.device, dtype=torch.float32)  # sector-aligned rows
     elif out is not None:
         y = out
     else:
@@ -315,6 +318,11 @@ def demod_coefficients_all(styles, wsqs, eps=1e-8):
         out.append(d)
     call("w2e_demod_all_fwd", descs, len(styles), b, float(eps), stream_ptr())
     return out
+
+
+def planar_pitch(w):
+    """W2E_PLANAR_PITCH (include/w2e.h): row pitch of the phase planes of the transposed-conv output for an input w wide."""
+    return (w + 1 + 15) & ~15
 
 
 def unplanar(t, in_w):

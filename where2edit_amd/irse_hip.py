@@ -44,7 +44,7 @@ def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out
         assert mode != K.MODE_UP and out.shape == (b, n_out, h, w) and out.is_contiguous()
         y = out
     elif mode == K.MODE_UP:
-        y = torch.empty((b, n_out, 2, 2, h + 1, (w + 4) & ~3), device=x.device, dtype=torch.float32)
+        y = torch.empty((b, n_out, 2, 2, h + 1, K.planar_pitch(w)), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
     call("w2e_conv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n_out, h, w, down_pad, ptr(bias), ptr(slope),
@@ -60,6 +60,9 @@ def affine_act(x, a=None, b=None, slope=None):
 
 def affine_act_bwd(gy, y, a, slope, batch, channels, height, width, planar=False):
     gx = torch.empty((batch, channels, height, width), device=gy.device, dtype=torch.float32)
+    if planar and tuple(gy.shape[-4:]) != (2, 2, height // 2 + 1, K.planar_pitch(width // 2)):
+        raise RuntimeError(f"affine_act_bwd: the phase-planar gradient of a {height}x{width} image must end in "
+                           f"[2,2,{height // 2 + 1},{K.planar_pitch(width // 2)}] (W2E_PLANAR_PITCH), got {tuple(gy.shape)}")
     call("w2e_affine_act_bwd", ptr(gy), ptr(y), ptr(a), ptr(slope), ptr(gx), batch, channels, height, width, int(planar), stream_ptr())
     return gx
 
