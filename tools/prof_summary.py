@@ -18,7 +18,8 @@ for r in rows:
     c, t = fam.get(key, (0, 0))
     fam[key] = (c + int(r["Calls"]), t + int(r["TotalDurationNs"]))
 print("# by kernel family: ms/step, calls/step, avg us, share")
-for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:18]:
+top = 18 if "--all" not in sys.argv else len(fam)  # --all: every kernel family (the launch tail)
+for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t / steps / 1e6:9.3f} {c / steps:8.1f} {t / c / 1e3:10.1f} {100.0 * t / tot:6.2f}%  {k}")
 print("# modconv instantiations <MODE,EPI,NOB,NPB,WO,WP,KC>")
 for r in rows:

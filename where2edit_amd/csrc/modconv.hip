@@ -61,7 +61,6 @@ struct ConvParams {
     int in_off;          // DOWN: the input origin is shifted by in_off (-1 = a stride-2 convolution with padding 1 of an in_h x in_w image)
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
     unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
-    int stagger_from, stagger_to, stagger_cycles;  // workgroups [from, to) of the grid start `stagger_cycles` late (see conv_impl)
 };
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3 };
@@ -87,7 +86,6 @@ __host__ __device__ constexpr bool is_up(int mode) { return mode == W2E_CONV_UP 
 
 // Upper bound of ceil(patch / threads) for a tile of `tm` pixels (the host refuses geometries beyond it).
 __host__ __device__ constexpr int max_patch_slots(int mode, int tm, int nt) {
-    if (nt == 1024) return mode == W2E_CONV_DOWN ? 3 : 1;  // (16-wave tiles of 512 / 256 pixels: patch <= 1024 elements)
     return mode == W2E_CONV_DOWN ? (nt == 512 ? (tm >= 1024 ? 9 : 5) : (tm >= 512 ? 9 : (tm >= 256 ? 5 : (tm >= 128 ? 3 : (tm >= 64 ? 2 : 1)))))
                                  : (nt == 512 ? (tm >= 2048 ? 5 : (tm >= 1024 ? 3 : 2)) : (tm >= 512 ? 3 : (tm >= 256 ? 2 : 1)));
 }
@@ -377,7 +375,7 @@ __device__ __forceinline__ void upconv_border(const ConvParams& p, float* smem, 
 }
 
 template <int MODE, int EPI, int NOB, int NPB, int WO, int WP, int KC, int DMA>
-__global__ __launch_bounds__(64 * WO * WP, (64 * WO * WP == 1024 ? 4 : 2)) void modconv_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) {
     constexpr int NT = 64 * WO * WP;  // 256 threads (small tiles, 2 workgroups/CU) or 512 (big tiles, 1/CU)
     constexpr int TN = 32 * NOB * WO;
     constexpr int NPX = (MODE == CONV_UPALL) ? NPB / 4 : NPB;  // pixel blocks per wave (UPALL: NPB = 4 phases x NPX)
@@ -403,13 +401,6 @@ __global__ __launch_bounds__(64 * WO * WP, (64 * WO * WP == 1024 ? 4 : 2)) void 
             return;
         }
         bid -= p.border_wgs;
-    }
-    // Stagger: the second workgroup of every CU starts late, so that the two co-resident workgroups are never in their prologue /
-    // epilogue / barrier bubbles together (workgroups dispatched later inherit the phase of the one whose slot they take).
-    if (p.stagger_cycles > 0 && (int)blockIdx.x >= p.stagger_from && (int)blockIdx.x < p.stagger_to) {
-        const unsigned long long wait = (unsigned long long)p.stagger_cycles * (unsigned)(((int)blockIdx.x - p.stagger_from) / 256 + 1);
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
     }
     // UP: phase-major grid, phase 0 (4 taps) first so the light phases fill the tail; (py,px) = (phase>>1, phase&1)
     const int per_phase = (gridDim.x - p.border_wgs) >> 2;
@@ -566,7 +557,7 @@ __global__ __launch_bounds__(64 * WO * WP, (64 * WO * WP == 1024 ? 4 : 2)) void 
             // the next chunk's loads are issued from inside the MFMA stream; the two waves that share a SIMD (w, w+4 in a
             // 512-thread workgroup) do it at different taps so that one of them always feeds the matrix pipe
             const bool do_pf = k0 + KCP < k_hi && !W2E_SKIP(p, 4);
-            const int my_pos = (NT >= 512) ? ((wave >> 2) & 1) : 0;
+            const int my_pos = (NT == 512) ? (wave >> 2) : 0;
             const float4 no_scale[KCP / 8] = {};
             mfma_chunk<MODE, NOB, NPB, KCP, TN, PY, PX, false, false>(acc, ws, xs, a_base, base, p.pw, p.plane, no_scale, [&](int pos) __attribute__((always_inline)) {
                 if (do_pf && pos == my_pos) prefetch(k0 + KCP);
@@ -688,7 +679,7 @@ __global__ __launch_bounds__(64 * WO * WP, (64 * WO * WP == 1024 ? 4 : 2)) void 
             const int ch = 8 * (e >> 3) + 2 * (e & 3) + ((e >> 2) & 1);
             stw[e] = ch < p.K ? (p.in_scale ? p.in_scale[(int64_t)b * p.K + ch] : 1.f) : 0.f;
         }
-        const int my_pos = (NT >= 512) ? ((swave >> 2) & 1) : 0;
+        const int my_pos = (NT == 512) ? (swave >> 2) : 0;
         if constexpr (DMA == 2) {
             // ---- opt-in (W2E_CONV_PRECISION=bf16x3): fp32 as three bf16 products on v_mfma_f32_32x32x16_bf16.  The chunk lands by
             // LDS-DMA in the fp32 layout (staging area S), is split into hi = bf16(a), lo = bf16(a - hi) while it is copied
@@ -801,7 +792,7 @@ __global__ __launch_bounds__(64 * WO * WP, (64 * WO * WP == 1024 ? 4 : 2)) void 
             constexpr int GROUPS = (KC / 8) * 9 * (MODE == CONV_UPALL ? NOB * (NPB / 4) : NOB * NPB);
             constexpr int PSTRIDE = GROUPS / NPIECE > 0 ? GROUPS / NPIECE : 1;             // a piece every PSTRIDE groups, or
             constexpr int PPG = NPIECE <= GROUPS ? 1 : (NPIECE + GROUPS - 1) / GROUPS;   // PPG pieces per group (most of them empty slots)
-            mfma_chunk<MODE, NOB, NPB, KC, TN, 0, 0, true, (NT == 512 || (NT == 256 && NOB * NPB >= 8))>(
+            mfma_chunk<MODE, NOB, NPB, KC, TN, 0, 0, true, (NT == 512)>(
                 acc, wsc, xsc, a_base, base, p.pw, p.plane, s4, [&](int) __attribute__((always_inline)) {},
                 [&](int g) __attribute__((always_inline)) {
                     if (g % PSTRIDE == 0 && (g / PSTRIDE) * PPG < NPIECE) {
@@ -1026,7 +1017,7 @@ static void launch_cfg(const ConvParams& p, int grid, size_t lds, hipStream_t s)
 // The LDS-DMA pipeline is instantiated for the tiles the high-resolution layers use; other tiles keep the register pipeline.
 static bool dma_has_cfg(bool all_phase, int cfg) {
     return all_phase ? (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 11)
-                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 12 || cfg == 13 || cfg == 14);
+                     : (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 8 || cfg == 9 || cfg == 10);
 }
 
 // opt-in bf16x3 form: the DOWN tile
@@ -1079,9 +1070,6 @@ static bool launch_mode_dma(int cfg, const ConvParams& p, int grid, size_t lds, 
             case 8: launch_cfg<MODE, EPI, 1, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
             case 9: launch_cfg<MODE, EPI, 2, 2, 2, 4, KC, 1>(p, grid, lds, s); return true;
             case 10: launch_cfg<MODE, EPI, 2, 2, 1, 8, KC, 1>(p, grid, lds, s); return true;
-            case 12: launch_cfg<MODE, EPI, 2, 4, 1, 4, KC, 1>(p, grid, lds, s); return true;
-            case 13: launch_cfg<MODE, EPI, 2, 2, 2, 8, KC, 1>(p, grid, lds, s); return true;
-            case 14: launch_cfg<MODE, EPI, 2, 2, 1, 16, KC, 1>(p, grid, lds, s); return true;
         }
         return false;
     }
@@ -1120,10 +1108,7 @@ static bool launch_mode(int cfg, const ConvParams& p, int grid, size_t lds, hipS
 static const TileCfg kCfgStd[] = {{2, 4, 2, 4}, {2, 4, 1, 8}, {1, 4, 1, 8},               // 512 threads, 1 workgroup / CU
                                    {2, 2, 2, 2}, {1, 4, 2, 2}, {1, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {1, 4, 1, 4},  // 256 threads
                                    {2, 2, 2, 4}, {2, 2, 1, 8},  // 512 threads, 4 accumulators per wave (register headroom)
-                                   {1, 8, 1, 8},                // all-phase UP only: 32 channels x (4 phases x 2 pixel blocks)
-                                   {2, 4, 1, 4},                // 256 threads, 8 accumulators per wave: 64 channels x 512 pixels, two per CU (DMA, staggered)
-                                   {2, 2, 2, 8},                // 1024 threads, 4 accumulators per wave: cfg 0's 128 x 512 tile on 16 waves (4 per SIMD)
-                                   {2, 2, 1, 16}};              // 1024 threads: cfg 1's 64 x 1024 tile on 16 waves
+                                   {1, 8, 1, 8}};               // all-phase UP only: 32 channels x (4 phases x 2 pixel blocks)
 static const int kNumCfg = 11;  // configurations of the per-phase / SAME / DOWN kernels
 static const int kNumCfgAll = 12;
 
@@ -1294,7 +1279,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
 #endif
     if (opt.tune_cfg >= 0) {  // tests / tools/layer_bench.py: "<cfg>[,<splits>[,<mode>]]", third field: only launches of that mode
         const int fc = opt.tune_cfg, fs = opt.tune_cfg_splits, fm = opt.tune_cfg_mode;
-        if ((fc < (use_all ? kNumCfgAll : ncfg) || (fc >= 12 && fc <= 14 && mode == W2E_CONV_SAME)) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
+        if (fc < (use_all ? kNumCfgAll : ncfg) && (fm < 0 || fm == mode)) best = fc, best_splits = fs > 0 ? fs : 1;
     }
     if (opt.deterministic) best_splits = 1;  // no fp32 atomics onto y: one workgroup owns every output element
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
@@ -1302,7 +1287,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const TileCfg cfg = cfgs[best];
     const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * (use_all ? cfg.npb / 4 : cfg.npb) * cfg.wp;
     p.tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
-    if (best == 12 && p.tw == 64) p.tw = 32;  // 16 x 32 pixels: the smaller patch (18 x 34) lets two workgroups' LDS stages share a CU
     p.th = tm / p.tw;
     p.tw_log2 = 0;
     while ((1 << p.tw_log2) < p.tw) ++p.tw_log2;
@@ -1321,7 +1305,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int tune_dma = opt.tune_dma;
     bool use_dma = false;
     size_t lds_dma = 0;
-    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && (best <= 2 || best >= 12));
+    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
     if (!prelu && (tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);
@@ -1373,16 +1357,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
         if (lds < (size_t)(nt_best / 64) * 32 * 64 * sizeof(float)) lds = (size_t)(nt_best / 64) * 32 * 64 * sizeof(float);  // their join buffer
     }
     const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
-    {
-        static const int tune_stagger = getenv("W2E_TUNE_STAGGER") ? atoi(getenv("W2E_TUNE_STAGGER")) : 0;  // EXPERIMENT
-        static const int tune_stagger_r = getenv("W2E_TUNE_STAGGER_R") ? atoi(getenv("W2E_TUNE_STAGGER_R")) : 2;  // workgroups per CU
-        if (tune_stagger > 0 && nt_best == 256) {
-            p.stagger_from = p.border_wgs + 256, p.stagger_to = p.border_wgs + 256 * tune_stagger_r;
-            p.stagger_cycles = (int)((int64_t)tune_stagger * ((k_ch + 7) / 8));  // per-chunk cycles x chunks
-        }
-    }
-    W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid too large");
-
 #ifdef W2E_TUNING
     // tuning aid: W2E_TUNE_CLOCK=1 stamps every workgroup and reports the in-kernel shader clock (s_memtime ticks per
     // 100 MHz s_memrealtime tick) of every 64th launch -- the DVFS-limited clock is what an MFMA-bound kernel is priced by
