@@ -232,6 +232,23 @@ int w2e_mapper_wgrad(const float* gy, const float* y, const float* h_in, float* 
 int w2e_mapper_gather(const float* src, float* dst, int batch, int n_latent, int groups, const int* l0, const int* len, void* stream);
 int w2e_mapper_transpose(const float* const* w, int count, float* wt, void* stream);
 
+/* The style-space mappers (mapper/latent_mappers.py:84-128: FullStyleSpaceMapper / WithoutToRGBStyleSpaceMapper): `groups` (<= 32)
+ * independent Mappers, Mapper c = PixelNorm over the dims[c] FEATURES of a [batch, dims[c]] code + 4 x EqualLinear(dims[c], dims[c],
+ * lr_mul 0.01, fused_lrelu); batch <= 16.  A layer of ALL codes is one launch per direction.  Activations are packed code-major:
+ * code c is the row-major [batch, dims[c]] block at float offset batch * sum_{i<c} dims[i]; weights / biases / gradients go by
+ * pointer array, w_scale[c] = that code's EqualLinear scale (lr_mul / sqrt(dims[c])), b_scale = lr_mul.
+ *   ssmapper_pixelnorm  h = packed PixelNorm of the code tensors x[c] ([batch, dims[c]] each)
+ *   ssmapper_gather     dst = packed copy of src[c] ([batch, dims[c]]; a null entry is packed as zeros)
+ *   ssmapper_linear     mode 0: out = lrelu(w_scale * a W^T + b_scale * bias) * sqrt2;
+ *                       mode 1: out = w_scale * (a .* lrelu'(y_act)) W   (the layer's input gradient)
+ *   ssmapper_wgrad      gw[c] = w_scale * (gy .* lrelu'(y))^T h_in,  gb[c] = b_scale * column sums of gy .* lrelu'(y) */
+int w2e_ssmapper_pixelnorm(const float* const* x, float* h, int batch, int groups, const int* dims, void* stream);
+int w2e_ssmapper_gather(const float* const* src, float* dst, int batch, int groups, const int* dims, void* stream);
+int w2e_ssmapper_linear(int mode, const float* a, const float* y_act, float* out, const float* const* w, const float* const* bias,
+                        int batch, int groups, const int* dims, const float* w_scale, float b_scale, void* stream);
+int w2e_ssmapper_wgrad(const float* gy, const float* y, const float* h_in, float* const* gw, float* const* gb, int batch, int groups,
+                       const int* dims, const float* w_scale, float b_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

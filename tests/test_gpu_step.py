@@ -256,8 +256,11 @@ def test_stylespace_step_matches_oracle():
     grads_o = torch.autograd.grad(loss_o, [osd[n] for n in names])
     # HIP
     codes_d = [s.to(DEV) for s in codes]
+    assert coach.merge_forward  # (the S-space step runs x and x_hat as one merged generator pass too: Coach.forward_pair)
     x, x_hat, w_hat = coach.forward_pair(codes_d)
     assert_close(x, x_o, 1e-4, "x = G(s)"), assert_close(x_hat, xh_o, 1e-4, "x_hat")
+    for a, b in zip(w_hat, wh_o):
+        assert_close(a, b, 1e-5, "edited S-space code")
     d = coach.train_step(codes_d)
     assert abs(float(d["loss"]) - loss_o.item()) <= 1e-4 * abs(loss_o.item())
     params = dict(coach.net.mapper.named_parameters())
@@ -649,6 +652,59 @@ def test_levels_mapper_kernels_equal_stock_composition(batch, no_medium, monkeyp
         assert not y_h[:, 4:8].any()
     for n, a, b in zip(names, g_h, g_s):
         assert_close(a, b, 2e-5, n)
+
+
+@pytest.mark.parametrize("kind,batch", [("single", 3), ("full", 2), ("without_torgb", 4), ("without_torgb", 16)])
+def test_single_and_stylespace_mapper_kernels_equal_stock_composition(kind, batch, monkeypatch):
+    """mapper_hip on the other three mappers of latent_mappers.py:33-44, 84-128: SingleMapper (LevelsMapper's kernels with one level
+    over all 18 latents) and the two style-space mappers (w2e_ssmapper_*: 26 / 17 Mappers of widths 512 ... 32, PixelNorm over the
+    features, a layer of all codes one launch per direction) -- outputs and every weight / bias gradient against the stock-op
+    composition of the same modules (W2E_MAPPER_STOCK=1), and the number of library launches the node makes."""
+    from where2edit_amd import _lib, latent_mappers as LM
+    opts = _opts()
+    torch.manual_seed(5)
+    cls = {"single": LM.SingleMapper, "full": LM.FullStyleSpaceMapper, "without_torgb": LM.WithoutToRGBStyleSpaceMapper}[kind]
+    m = cls(opts).to(DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.ndim == 1:
+                p.normal_(0, 30.0)  # (biases are multiplied by lr_mul = 0.01)
+    gen = torch.Generator().manual_seed(2)
+    if kind == "single":
+        x = seeded.wplus_latents(batch, 18, salt=6).to(DEV)
+        r = torch.randn(batch, 18, 512, generator=gen).to(DEV)
+    else:
+        x = [torch.randn(batch, 1, c, 1, 1, generator=gen).to(DEV) for c in LM.STYLESPACE_DIMENSIONS]
+        r = [torch.randn(batch, 1, c, 1, 1, generator=gen).to(DEV) for c in LM.STYLESPACE_DIMENSIONS]
+    names = [n for n, _ in m.named_parameters()]
+    calls = []
+    real_call = _lib.call
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        loss = (y * r).sum() if kind == "single" else sum((a * b).sum() for a, b in zip(y, r))
+        loss.backward()
+        ys = [y] if kind == "single" else list(y)
+        return [t.detach().clone() for t in ys], [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+
+    import where2edit_amd.mapper_hip as MH
+    monkeypatch.setattr(MH, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+    y_h, g_h = run()
+    n_hip = len(calls)
+    monkeypatch.setenv("W2E_MAPPER_STOCK", "1")
+    y_s, g_s = run()
+    assert len(calls) == n_hip, "the stock composition must not go through the mapper kernels"
+    # forward: pixelnorm + 4 layers; backward: (gather +) 4 weight-gradient launches + 3 input-gradient launches (+ transposes)
+    assert 12 <= n_hip <= 16, n_hip
+    for a, b in zip(y_h, y_s):
+        assert_close(a, b, 1e-5, f"{kind} mapper output")
+    if kind == "without_torgb":
+        assert not any(y_h[c].any() for c in range(1, len(LM.STYLESPACE_DIMENSIONS), 3)), "ToRGB codes map to zeros"
+    for n, a, b in zip(names, g_h, g_s):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            assert_close(a, b, 2e-5, n)
 
 
 def test_merged_forward_equals_two_passes():

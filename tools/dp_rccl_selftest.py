@@ -12,14 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 SIZE = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1)
+from where2edit_amd import dist as wd  # noqa: E402
+
+wd.init_from_env(backend="nccl", timeout_s=300, force_group=True)  # the very call bench.py makes (device_id, timeout)
 import bench  # noqa: E402
 
 coach = bench.build_coach(SIZE, B, "cuda:0", True, "hip")
 w = bench.synthetic_latents(coach.net.decoder, B, 0)
 for _ in range(3):
     d = coach.train_step(w)
+dist.all_reduce(coach.bucket.flat)  # (GradBucket.all_reduce_mean skips the collective at world size 1: issue it here)
 dist.barrier()
 torch.cuda.synchronize()
 print("RCCL world-1 DP eager step ok, loss", float(d["loss"]), "bucket MB", coach.bucket.nbytes / 1e6, flush=True)

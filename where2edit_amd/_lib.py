@@ -29,6 +29,10 @@ _PROTOS = {
     "w2e_mapper_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P]),
     "w2e_mapper_gather": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "w2e_mapper_transpose": (_I, [_P, _I, _P, _P]),
+    "w2e_ssmapper_pixelnorm": (_I, [_P, _P, _I, _I, _P, _P]),
+    "w2e_ssmapper_gather": (_I, [_P, _P, _I, _I, _P, _P]),
+    "w2e_ssmapper_linear": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _P]),
+    "w2e_ssmapper_wgrad": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _P]),
     "w2e_bias_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
     "w2e_bias_act_bwd": (_I, [_P, _P, _P, _L, _F, _F, _P]),
     "w2e_bias_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),

@@ -89,6 +89,17 @@ class Coach:
             x_hat, w_hat, _ = dec([w_hat], input_is_latent=True, return_latents=True, randomize_noise=False, truncation=1,
                                   attention_layer=att_layer, attention_map=mask, feature_map=feats)
             return x, x_hat, w_hat
+        if self.merge_forward and self._side is None and s_space and torch.is_grad_enabled():
+            # the same merged pass for S-space codes (coach.py:84-89 with work_in_stylespace): every code tensor is [c; c_hat]
+            from . import functional as K
+            n = w[0].shape[0]
+            delta = self.net.mapper(w)
+            w_hat = [c + 0.1 * dc for c, dc in zip(w, delta)]
+            with K.nograd_prefix(n):
+                both, _, codes = dec([[torch.cat([c.detach(), ch]) for c, ch in zip(w, w_hat)]], input_is_latent=True, return_latents=True,
+                                     randomize_noise=False, truncation=1, input_is_stylespace=True)
+            self._x_ready = None
+            return both[:n].detach(), K.tail_rows(both, n), [c[n:] for c in codes]
         if self.merge_forward and self._side is None and not s_space and torch.is_grad_enabled():
             # x = G(w) (no grad) and x_hat = G(w_hat) as ONE generator pass over [w; w_hat]: twice the rows per launch (the
             # same kernels run ~9 % faster per image at twice the batch) and half the forward launches.  Values are the ones of

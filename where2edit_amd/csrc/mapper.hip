@@ -260,3 +260,203 @@ extern "C" int w2e_mapper_transpose(const float* const* w, int count, float* wt,
     W2E_LAUNCH_CHECK("mapper_transpose");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The STYLE-SPACE mappers (mapper/latent_mappers.py:84-128: FullStyleSpaceMapper / WithoutToRGBStyleSpaceMapper): one Mapper per
+// S-space code c, Mapper(latent_dim = C_c) = PixelNorm over the C_c FEATURES of a [B, C_c] input (dim = 1 of a 2-D tensor) + 4 x
+// EqualLinear(C_c, C_c, lr_mul 0.01, fused_lrelu), C_c in {512, 256, 128, 64, 32}.  26 (17) independent MLPs on B rows each: as stock
+// ops ~20 launches per code and direction.  Here a layer of ALL codes is one launch per direction (the code of a workgroup is
+// blockIdx.y); activations are packed code-major, code c at float offset B * sum_{i<c} C_i, row-major [B, C_c].
+namespace w2e {
+
+constexpr int SS_MAXG = 32, SS_MAXB = 16;
+struct SsGroups {
+    int groups, batch;
+    int dim[SS_MAXG], off[SS_MAXG];        // feature count of a code, float offset of its [batch, dim] block in the packed buffers
+    const float* w[SS_MAXG];               // this layer's weight [dim, dim] (row n = output feature n)
+    const float* bias[SS_MAXG];            // [dim]
+    const float* src[SS_MAXG];             // pixelnorm: the code tensors [batch, dim]; gather: the incoming gradients (null = zeros)
+    float* gw[SS_MAXG];
+    float* gb[SS_MAXG];
+    float w_scale[SS_MAXG];                // EqualLinear's scale = lr_mul / sqrt(dim): differs from code to code
+};
+
+// h[off_c + b*C + k] = x_c[b, k] * rsqrt(mean_k x_c[b, k]^2 + 1e-8)     (one wave per (code, row))
+__global__ __launch_bounds__(256) void ss_pixelnorm_kernel(SsGroups g, float* __restrict__ h) {
+    const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int d = g.dim[c];
+    for (int b = blockIdx.x * 4 + wave; b < g.batch; b += gridDim.x * 4) {
+        const float* xp = g.src[c] + (int64_t)b * d;
+        float s = 0.f;
+        for (int k = lane; k < d; k += 64) s += xp[k] * xp[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float r = rsqrtf(s / d + 1e-8f);
+        float* hp = h + g.off[c] + (int64_t)b * d;
+        for (int k = lane; k < d; k += 64) hp[k] = xp[k] * r;
+    }
+}
+
+// packed copy of a list of [batch, dim] tensors (the incoming gradients of the backward; a null entry = zeros)
+__global__ __launch_bounds__(256) void ss_gather_kernel(SsGroups g, float* __restrict__ dst) {
+    const int c = blockIdx.y, n = g.batch * g.dim[c];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) dst[g.off[c] + e] = g.src[c] ? g.src[c][e] : 0.f;
+}
+
+// forward layer: out[m, n] = lrelu(w_scale * sum_k a[m, k] W[n, k] + b_scale * bias[n]) * sqrt2.  One wave per output feature n
+// (4 per workgroup): the lanes split k (coalesced weight-row reads), every row m of the code is accumulated in a register.
+__global__ __launch_bounds__(256) void ss_linear_fwd_kernel(SsGroups g, const float* __restrict__ a, float* __restrict__ out, float b_scale) {
+    const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int d = g.dim[c], n = blockIdx.x * 4 + wave;
+    if (n >= d) return;
+    const float* wr = g.w[c] + (int64_t)n * d;
+    const float* ap = a + g.off[c];
+    float acc[SS_MAXB];
+#pragma unroll
+    for (int m = 0; m < SS_MAXB; ++m) acc[m] = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int m = 0; m < SS_MAXB; ++m)
+            if (m < g.batch) acc[m] += ap[(int64_t)m * d + k] * wv;
+    }
+    const float bs = g.bias[c] ? g.bias[c][n] * b_scale : 0.f;
+#pragma unroll
+    for (int m = 0; m < SS_MAXB; ++m) {
+        if (m >= g.batch) break;
+        float s = acc[m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        float v = s * g.w_scale[c] + bs;
+        v = (v > 0.f ? v : v * MAP_SLOPE) * MAP_GAIN;
+        if (lane == 0) out[g.off[c] + (int64_t)m * d + n] = v;
+    }
+}
+
+// input gradient of a layer: gx[m, i] = w_scale * sum_o gpre[m, o] W[o, i],  gpre = gy .* lrelu'(y).  A thread owns input feature i
+// (weight rows are read coalesced across i); gpre of the code is staged in LDS.
+__global__ __launch_bounds__(256) void ss_linear_bwd_kernel(SsGroups g, const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx) {
+    extern __shared__ float gp[];  // [batch][d]
+    const int c = blockIdx.y, d = g.dim[c], i0 = blockIdx.x * 256;
+    if (i0 >= d) return;
+    for (int e = threadIdx.x; e < g.batch * d; e += 256) {
+        const float yv = y[g.off[c] + e];
+        gp[e] = gy[g.off[c] + e] * MAP_GAIN * (yv > 0.f ? 1.f : MAP_SLOPE);
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    if (i >= d) return;
+    float acc[SS_MAXB];
+#pragma unroll
+    for (int m = 0; m < SS_MAXB; ++m) acc[m] = 0.f;
+    const float* W = g.w[c];
+    for (int o = 0; o < d; ++o) {
+        const float wv = W[(int64_t)o * d + i];
+#pragma unroll
+        for (int m = 0; m < SS_MAXB; ++m)
+            if (m < g.batch) acc[m] += gp[m * d + o] * wv;
+    }
+#pragma unroll
+    for (int m = 0; m < SS_MAXB; ++m)
+        if (m < g.batch) gx[g.off[c] + (int64_t)m * d + i] = acc[m] * g.w_scale[c];
+}
+
+// weight / bias gradients of a layer: gW[o, i] = w_scale * sum_m gpre[m, o] h_in[m, i],  gb[o] = b_scale * sum_m gpre[m, o]
+// (a thread owns one (o, i); rows summed in ascending order: deterministic)
+__global__ __launch_bounds__(256) void ss_wgrad_kernel(SsGroups g, const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ h_in,
+                                                      float b_scale) {
+    const int c = blockIdx.y, d = g.dim[c];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)d * d) return;
+    const int o = (int)(e / d), i = (int)(e - (int64_t)o * d);
+    float s = 0.f, sb = 0.f;
+    for (int m = 0; m < g.batch; ++m) {
+        const int64_t at = g.off[c] + (int64_t)m * d;
+        const float gv = gy[at + o] * MAP_GAIN * (y[at + o] > 0.f ? 1.f : MAP_SLOPE);
+        s += gv * h_in[at + i];
+        sb += gv;
+    }
+    g.gw[c][e] = s * g.w_scale[c];
+    if (i == 0 && g.gb[c]) g.gb[c][o] = sb * b_scale;
+}
+
+static bool ss_fill(SsGroups& g, int groups, int batch, const int* dims) {
+    if (groups < 1 || groups > SS_MAXG || batch < 1 || batch > SS_MAXB) return false;
+    g.groups = groups, g.batch = batch;
+    int off = 0;
+    for (int c = 0; c < groups; ++c) {
+        if (dims[c] < 1 || dims[c] > 4096) return false;
+        g.dim[c] = dims[c], g.off[c] = off;
+        off += batch * dims[c];
+        g.w[c] = g.bias[c] = g.src[c] = nullptr, g.gw[c] = g.gb[c] = nullptr;
+        g.w_scale[c] = 1.f;
+    }
+    return true;
+}
+static int ss_maxdim(const SsGroups& g) {
+    int m = 0;
+    for (int c = 0; c < g.groups; ++c) m = g.dim[c] > m ? g.dim[c] : m;
+    return m;
+}
+
+}  // namespace w2e
+
+extern "C" int w2e_ssmapper_pixelnorm(const float* const* x, float* h, int batch, int groups, const int* dims, void* stream) {
+    W2E_REQUIRE(x && h && dims, "ssmapper_pixelnorm: null argument");
+    SsGroups g{};
+    W2E_REQUIRE(ss_fill(g, groups, batch, dims), "ssmapper_pixelnorm: 1..32 codes, batch 1..16");
+    for (int c = 0; c < groups; ++c) {
+        W2E_REQUIRE(x[c], "ssmapper_pixelnorm: null code tensor");
+        g.src[c] = x[c];
+    }
+    ss_pixelnorm_kernel<<<dim3((unsigned)ceil_div(batch, 4), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(g, h);
+    W2E_LAUNCH_CHECK("ssmapper_pixelnorm");
+    return 0;
+}
+
+extern "C" int w2e_ssmapper_gather(const float* const* src, float* dst, int batch, int groups, const int* dims, void* stream) {
+    W2E_REQUIRE(src && dst && dims, "ssmapper_gather: null argument");
+    SsGroups g{};
+    W2E_REQUIRE(ss_fill(g, groups, batch, dims), "ssmapper_gather: 1..32 codes, batch 1..16");
+    for (int c = 0; c < groups; ++c) g.src[c] = src[c];
+    ss_gather_kernel<<<dim3((unsigned)ceil_div((int64_t)batch * ss_maxdim(g), 256), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(g, dst);
+    W2E_LAUNCH_CHECK("ssmapper_gather");
+    return 0;
+}
+
+extern "C" int w2e_ssmapper_linear(int mode, const float* a, const float* y_act, float* out, const float* const* w, const float* const* bias,
+                                   int batch, int groups, const int* dims, const float* w_scale, float b_scale, void* stream) {
+    W2E_REQUIRE(a && out && w && dims && w_scale, "ssmapper_linear: null argument");
+    W2E_REQUIRE(mode == 0 || (mode == 1 && y_act), "ssmapper_linear: mode 0 (forward) or 1 (input gradient, needs the layer output)");
+    SsGroups g{};
+    W2E_REQUIRE(ss_fill(g, groups, batch, dims), "ssmapper_linear: 1..32 codes, batch 1..16");
+    for (int c = 0; c < groups; ++c) {
+        W2E_REQUIRE(w[c], "ssmapper_linear: null weight");
+        g.w[c] = w[c], g.bias[c] = (mode == 0 && bias) ? bias[c] : nullptr, g.w_scale[c] = w_scale[c];
+    }
+    const int dmax = ss_maxdim(g);
+    if (mode == 0) {
+        ss_linear_fwd_kernel<<<dim3((unsigned)ceil_div(dmax, 4), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(g, a, out, b_scale);
+    } else {
+        const size_t lds = sizeof(float) * (size_t)batch * dmax;
+        W2E_REQUIRE(lds <= 64 * 1024, "ssmapper_linear: batch x width too large for the staged gradient");
+        ss_linear_bwd_kernel<<<dim3((unsigned)ceil_div(dmax, 256), (unsigned)groups), 256, lds, (hipStream_t)stream>>>(g, a, y_act, out);
+    }
+    W2E_LAUNCH_CHECK("ssmapper_linear");
+    return 0;
+}
+
+extern "C" int w2e_ssmapper_wgrad(const float* gy, const float* y, const float* h_in, float* const* gw, float* const* gb, int batch, int groups,
+                                  const int* dims, const float* w_scale, float b_scale, void* stream) {
+    W2E_REQUIRE(gy && y && h_in && gw && dims && w_scale, "ssmapper_wgrad: null argument");
+    SsGroups g{};
+    W2E_REQUIRE(ss_fill(g, groups, batch, dims), "ssmapper_wgrad: 1..32 codes, batch 1..16");
+    for (int c = 0; c < groups; ++c) {
+        W2E_REQUIRE(gw[c], "ssmapper_wgrad: null weight gradient");
+        g.gw[c] = gw[c], g.gb[c] = gb ? gb[c] : nullptr, g.w_scale[c] = w_scale[c];
+    }
+    const int dmax = ss_maxdim(g);
+    ss_wgrad_kernel<<<dim3((unsigned)ceil_div((int64_t)dmax * dmax, 256), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(g, gy, y, h_in, b_scale);
+    W2E_LAUNCH_CHECK("ssmapper_wgrad");
+    return 0;
+}

@@ -1300,12 +1300,13 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     const int nt_best = 64 * cfg.wo * cfg.wp;
     // LDS-DMA pipeline (two LDS stages + the in_scale table): where it is instantiated and fits
     // W2E_TUNE_DMA: 0 never, 1 wherever instantiated; default = where it measured faster (tools/layer_bench.py, batch 4):
-    // the 512-thread 8-accumulator SAME tiles (+1.5-3 %) and the all-phase UP tiles 0 / 1 at K >= 256 (+2-3 %); not DOWN (-1-2 %), not the
+    // the 512-thread 8-accumulator SAME tiles (+1.5-3 %) and the all-phase UP tiles 0 / 1 / 11 (+2-5 %; since the DMA is issued piecewise
+    // through inline asm also at K < 256); not DOWN (-1-2 %), not the
     // 256-thread 32x512 tile of the 1024^2 layer (two LDS stages leave room for 2 instead of 3 workgroups per CU: -11 %)
     const int tune_dma = opt.tune_dma;
     bool use_dma = false;
     size_t lds_dma = 0;
-    const bool dma_auto = prelu ? false : use_all ? (best == 0 || (best == 1 && k_ch >= 256)) : (mode == W2E_CONV_SAME && best <= 2);
+    const bool dma_auto = prelu ? false : use_all ? (best == 0 || best == 1 || best == 11) : (mode == W2E_CONV_SAME && best <= 2);
     if (!prelu && (tune_dma == 1 || (tune_dma < 0 && dma_auto)) && !(up && !use_all) && dma_has_cfg(use_all, best)) {
         const int plane16 = (p.plane + 15) & ~15;  // whole DMA wave-instructions (16 pixels x 4 channels) per plane
         lds_dma = sizeof(float) * (2 * ((size_t)kc * 9 * tn + (size_t)kc * plane16) + (size_t)((k_ch + 7) / 8) * 8);

@@ -12,14 +12,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, timeout_s=None):
+def init_from_env(backend=None, timeout_s=None, force_group=False):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
     Returns (rank, world_size, local_rank).  World size 1 needs no process group.  `timeout_s`: the process group's
-    collective timeout (a benchmark wants a rank that lost its partners to fail in minutes, not in the default 10-30)."""
+    collective timeout (a benchmark wants a rank that lost its partners to fail in minutes, not in the default 10-30).
+    `force_group`: create the group at world size 1 too (tools/dp_rccl_selftest.py: the RCCL code path on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
         kw = {}

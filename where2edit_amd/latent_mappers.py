@@ -81,6 +81,11 @@ class SingleMapper(Module):
         self.mapping = Mapper(opts)
 
     def forward(self, x):
+        if x.is_cuda and x.ndim == 3 and not os.environ.get("W2E_MAPPER_STOCK"):
+            from . import mapper_hip  # one Mapper over all latents = LevelsMapper's kernels with a single level
+            out = mapper_hip.levels_mlp(x, [(self.mapping, 0, x.shape[1])])
+            if out is not None:
+                return out
         return self.mapping(x)
 
 
@@ -127,6 +132,11 @@ class FullStyleSpaceMapper(Module):
             setattr(self, f"mapper_{c}", Mapper(opts, latent_dim=c_dim))
 
     def forward(self, x):
+        if x and x[0].is_cuda and not os.environ.get("W2E_MAPPER_STOCK"):
+            from . import mapper_hip  # the 26 MLPs as one node on the library's style-space mapper kernels (w2e_ssmapper_*)
+            out = mapper_hip.stylespace_mlp(list(x), [getattr(self, f"mapper_{c}") for c in range(len(x))])
+            if out is not None:
+                return out
         out = []
         for c, x_c in enumerate(x):
             out.append(getattr(self, f"mapper_{c}")(x_c.view(x_c.shape[0], -1)).view(x_c.shape))
@@ -146,6 +156,13 @@ class WithoutToRGBStyleSpaceMapper(Module):
             setattr(self, f"mapper_{c}", Mapper(opts, latent_dim=STYLESPACE_DIMENSIONS[c]))
 
     def forward(self, x):
+        if x and x[0].is_cuda and not os.environ.get("W2E_MAPPER_STOCK"):
+            from . import mapper_hip  # the 17 MLPs as one node (w2e_ssmapper_*); the ToRGB codes map to zeros
+            idx = self.STYLESPACE_INDICES_WITHOUT_TORGB
+            mapped = mapper_hip.stylespace_mlp([x[c] for c in idx], [getattr(self, f"mapper_{c}") for c in idx])
+            if mapped is not None:
+                by_c = dict(zip(idx, mapped))
+                return [by_c[c] if c in by_c else torch.zeros_like(x[c]) for c in range(len(STYLESPACE_DIMENSIONS))]
         out = []
         for c in range(len(STYLESPACE_DIMENSIONS)):
             x_c = x[c]

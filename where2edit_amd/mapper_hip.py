@@ -111,3 +111,98 @@ def levels_mlp(x, mappers_and_ranges):
     biases = [layers[gi][j].bias for j in range(LAYERS) for gi in range(len(layers))]
     levels = tuple((l0, ln) for _, l0, ln in mappers_and_ranges)
     return _LevelsMLP.apply(x, levels, first.scale, first.lr_mul, *weights, *biases)
+
+
+# ---- the style-space mappers (latent_mappers.py:84-128): one Mapper per S-space code, width = that code's channel count ----------
+def _float_array(values):
+    return (ctypes.c_float * len(values))(*values)
+
+
+class _StyleSpaceMLP(torch.autograd.Function):
+    """out_c = Mapper_c(x_c) for G codes x_c [B, C_c] (PixelNorm over the features + 4 EqualLinear(C_c, C_c, fused_lrelu)), every
+    layer of ALL codes one launch per direction (w2e_ssmapper_*).  `params`: LAYERS * G weights (layer-major), then the biases in
+    the same order.  Returns G tensors [B, C_c] (views of one packed buffer).  Differentiable in the parameters only."""
+
+    @staticmethod
+    def forward(ctx, dims, w_scales, b_scale, n_codes, *args):
+        xs, params = args[:n_codes], args[n_codes:]
+        g = n_codes
+        b = xs[0].shape[0]
+        dev = xs[0].device
+        total = b * sum(dims)
+        dims_c, ws_c = _int_array(dims), _float_array(w_scales)
+        weights, biases = params[:LAYERS * g], params[LAYERS * g:]
+        h = [torch.empty(total, device=dev, dtype=torch.float32) for _ in range(LAYERS + 1)]  # h[0] = PixelNorm(x), h[j+1] = layer j's output
+        st = stream_ptr()
+        xs = [x.contiguous() for x in xs]
+        call("w2e_ssmapper_pixelnorm", _ptr_array(xs), ptr(h[0]), b, g, dims_c, st)
+        for j in range(LAYERS):
+            call("w2e_ssmapper_linear", 0, ptr(h[j]), None, ptr(h[j + 1]), _ptr_array(weights[j * g:(j + 1) * g]),
+                 _ptr_array(biases[j * g:(j + 1) * g]), b, g, dims_c, ws_c, float(b_scale), st)
+        ctx.save_for_backward(*h, *weights)
+        ctx.geom = (tuple(dims), tuple(w_scales), b_scale, b)
+        outs, off = [], 0
+        for d in dims:
+            outs.append(h[LAYERS][off:off + b * d].view(b, d))
+            off += b * d
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        dims, w_scales, b_scale, b = ctx.geom
+        g = len(dims)
+        saved = ctx.saved_tensors
+        h, weights = saved[:LAYERS + 1], saved[LAYERS + 1:]
+        dev = h[0].device
+        dims_c, ws_c = _int_array(dims), _float_array(w_scales)
+        st = stream_ptr()
+        gsrc = [go.contiguous() if go is not None else None for go in gouts]
+        gy = torch.empty_like(h[0])
+        call("w2e_ssmapper_gather", _ptr_array(gsrc), ptr(gy), b, g, dims_c, st)
+        gw = [torch.empty((d, d), device=dev, dtype=torch.float32) for _ in range(LAYERS) for d in dims]
+        gb = [torch.empty((d,), device=dev, dtype=torch.float32) for _ in range(LAYERS) for d in dims]
+        for j in range(LAYERS - 1, -1, -1):
+            call("w2e_ssmapper_wgrad", ptr(gy), ptr(h[j + 1]), ptr(h[j]), _ptr_array(gw[j * g:(j + 1) * g]), _ptr_array(gb[j * g:(j + 1) * g]),
+                 b, g, dims_c, ws_c, float(b_scale), st)
+            if j == 0:
+                break
+            gx = torch.empty_like(gy)
+            call("w2e_ssmapper_linear", 1, ptr(gy), ptr(h[j + 1]), ptr(gx), _ptr_array(weights[j * g:(j + 1) * g]), None, b, g, dims_c, ws_c,
+                 0.0, st)
+            gy = gx
+        return (None, None, None, None, *([None] * g), *gw, *gb)
+
+
+def stylespace_mlp(xs, mappers):
+    """xs: the G code tensors (any shape with B leading and C_c elements per sample), mappers: their G `Mapper`s -> list of G outputs
+    shaped like the inputs, or None when this path does not apply (CPU tensors, codes that require grad, batch > 16, more than 32
+    codes, a Mapper that is not PixelNorm + 4 x EqualLinear(C, C, fused_lrelu) with one lr_mul): the caller then composes the stock
+    modules."""
+    from .stylegan2 import EqualLinear, PixelNorm
+    if not xs or len(xs) != len(mappers) or len(xs) > 32:
+        return None
+    b = xs[0].shape[0]
+    if b < 1 or b > 16:
+        return None
+    dims, layers = [], []
+    for x, mp in zip(xs, mappers):
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.shape[0] == b) or x.requires_grad:
+            return None
+        seq = list(mp.mapping)
+        lin = seq[1:]
+        d = x.numel() // b
+        if not (isinstance(seq[0], PixelNorm) and seq[0].dim == 1 and len(lin) == LAYERS and all(isinstance(m, EqualLinear) for m in lin)):
+            return None
+        if any(m.weight.shape != (d, d) or m.bias is None or m.activation != "fused_lrelu" or not m.weight.is_cuda for m in lin):
+            return None
+        dims.append(d)
+        layers.append(lin)
+    lr_mul = layers[0][0].lr_mul
+    if any(m.lr_mul != lr_mul for lin in layers for m in lin) or any(lin[j].scale != lin[0].scale for lin in layers for j in range(LAYERS)):
+        return None
+    w_scales = [lin[0].scale for lin in layers]
+    weights = [layers[gi][j].weight for j in range(LAYERS) for gi in range(len(layers))]
+    biases = [layers[gi][j].bias for j in range(LAYERS) for gi in range(len(layers))]
+    outs = _StyleSpaceMLP.apply(dims, w_scales, lr_mul, len(xs), *[x.reshape(b, -1) for x in xs], *weights, *biases)
+    return [o.view(x.shape) for o, x in zip(outs, xs)]

@@ -36,13 +36,46 @@ def invalidate_caches(module):
             m._text_cache = None
 
 
-def _frozen_weight(mod, what):
-    """The 3x3 / 1x1 conv weights are consumed as packed, detached copies: there is no weight-gradient kernel (the decoder
-    is never optimised on this path, coach.py:174-180).  Refuse, loudly, to run in a mode where autograd would expect one."""
-    if torch.is_grad_enabled() and mod.weight.requires_grad:
-        raise RuntimeError(f"{what}: the conv weight requires grad, but where2edit_amd computes no conv-weight gradients "
-                           "(frozen-decoder path).  Call decoder.requires_grad_(False) (Coach does), or run under "
-                           "torch.no_grad(); modulation / noise / bias / ToRGB parameters may stay trainable.")
+_WARNED_TRAINABLE = False
+
+
+def _trainable_weight(mod):
+    """True when autograd expects a gradient for this conv weight.  The packed-weight kernels (K1) compute none -- the path this
+    package accelerates never optimises the decoder (coach.py:174-180) -- so such a layer runs `_modconv_trainable` below, the
+    reference's own composition on stock PyTorch-ROCm ops, announced once."""
+    global _WARNED_TRAINABLE
+    if not (torch.is_grad_enabled() and mod.weight.requires_grad):
+        return False
+    if not _WARNED_TRAINABLE:
+        import warnings
+        warnings.warn("where2edit_amd: a ModulatedConv2d weight requires grad (decoder fine-tuning): that layer runs as the "
+                      "reference's per-sample-weight grouped convolution on stock PyTorch-ROCm ops (MIOpen), not on the HIP "
+                      "kernels.  Call decoder.requires_grad_(False) / stylegan2.freeze_conv_weights() for the fast path.")
+        _WARNED_TRAINABLE = True
+    return True
+
+
+def _modconv_trainable(mod, input, style):
+    """model.py:239-276 for a weight that is being trained: per-sample weights, one grouped (transposed) convolution, autograd
+    through everything.  `style` is the post-affine [B,1,Cin,1,1] tensor.  The FIR of the up/down-sampling branches is the HIP
+    upfirdn2d op (differentiable in its input)."""
+    batch, cin, height, width = input.shape
+    cout, k = mod.out_channel, mod.kernel_size
+    weight = mod.scale * mod.weight * style
+    if mod.demodulate:
+        weight = weight * torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + mod.eps).view(batch, cout, 1, 1, 1)
+    x = input.reshape(1, batch * cin, height, width)
+    if mod.upsample:
+        wt = weight.transpose(1, 2).reshape(batch * cin, cout, k, k)
+        out = F.conv_transpose2d(x, wt, padding=0, stride=2, groups=batch)
+        return mod.blur(out.view(batch, cout, out.shape[2], out.shape[3]))
+    if mod.downsample:
+        x = mod.blur(input)
+        out = F.conv2d(x.reshape(1, batch * cin, x.shape[2], x.shape[3]), weight.view(batch * cout, cin, k, k), padding=0, stride=2,
+                       groups=batch)
+        return out.view(batch, cout, out.shape[2], out.shape[3])
+    out = F.conv2d(x, weight.view(batch * cout, cin, k, k), padding=mod.padding, groups=batch)
+    return out.view(batch, cout, out.shape[2], out.shape[3])
 
 
 def freeze_conv_weights(module):
@@ -248,9 +281,10 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input, style, input_is_stylespace=False):
         if self.kernel_size not in (1, 3):
             raise NotImplementedError("ModulatedConv2d kernels exist for kernel_size 1 and 3 (the sizes the generator uses)")
-        _frozen_weight(self, "ModulatedConv2d")
         batch, in_channel, height, width = input.shape
         style = self._style(style, batch, input_is_stylespace)
+        if _trainable_weight(self):
+            return _modconv_trainable(self, input, style), style
         s2d = style.reshape(batch, in_channel)
         fwd, bwd, wsq = self._derived()
         if not self.demodulate:
@@ -308,7 +342,7 @@ class StyledConv(nn.Module):
         conv = self.conv
         batch = input.shape[0]
         fusable = (conv.kernel_size == 3 and not conv.downsample and noise is not None and noise.ndim == 4
-                   and noise.shape[0] == 1 and noise.shape[1] == 1
+                   and noise.shape[0] == 1 and noise.shape[1] == 1 and not _trainable_weight(conv)
                    and not (conv.upsample and tuple(conv.blur.kernel.shape) != (4, 4)))
         self._act_noise = None  # (set below when the fused epilogue produced the output: what a following ToRGB may fold, see _synthesis)
         if not fusable:
@@ -316,7 +350,6 @@ class StyledConv(nn.Module):
             out, style = conv(input, style, input_is_stylespace=input_is_stylespace)
             out = self.noise(out, noise=noise)
             return self.activate(out), style
-        _frozen_weight(conv, "StyledConv")
         style = conv._style(style, batch, input_is_stylespace)
         s2d = style.reshape(batch, conv.in_channel)
         fwd, bwd, wsq = conv._derived()
