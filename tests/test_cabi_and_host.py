@@ -158,17 +158,21 @@ def test_irse50_backbone_matches_reference_fixture():
     assert abs(float(l_same)) < 1e-5 and zero == 0
 
 
-def test_trainable_conv_weight_is_refused_not_silently_ignored():
-    """There is no conv-weight gradient kernel (the decoder is frozen on this path, coach.py:174-180): a 3x3 weight that
-    requires grad must raise instead of training 'partially'.  The check runs before any GPU call."""
+def test_trainable_conv_weight_never_computes_on_the_cpu():
+    """A 3x3 weight that requires grad (decoder fine-tuning) routes the layer to the per-sample-weight composition on stock GPU ops
+    (announced by a warning; the weight gradients are tested against the oracle on the GPU).  Neither that path nor the frozen
+    fast path may compute on CPU tensors: both refuse them."""
+    import warnings
     from where2edit_amd.stylegan2 import ModulatedConv2d, StyledConv, freeze_conv_weights
     x, w = torch.randn(1, 8, 4, 4), torch.randn(1, 512)
     for m in (ModulatedConv2d(8, 8, 3, 512), StyledConv(8, 8, 3, 512)):
-        with pytest.raises(RuntimeError, match="no conv-weight gradients"):
-            m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with pytest.raises(RuntimeError, match="GPU only"):
+                m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
         freeze_conv_weights(m)
         assert m.noise.weight.requires_grad if isinstance(m, StyledConv) else m.modulation.weight.requires_grad
-        with pytest.raises(RuntimeError, match="GPU only"):  # past the guard now: the kernels refuse CPU tensors
+        with pytest.raises(RuntimeError, match="GPU only"):  # the kernels refuse CPU tensors
             m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
 
 

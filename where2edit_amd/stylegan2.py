@@ -59,6 +59,8 @@ def _modconv_trainable(mod, input, style):
     """model.py:239-276 for a weight that is being trained: per-sample weights, one grouped (transposed) convolution, autograd
     through everything.  `style` is the post-affine [B,1,Cin,1,1] tensor.  The FIR of the up/down-sampling branches is the HIP
     upfirdn2d op (differentiable in its input)."""
+    if not input.is_cuda:
+        raise RuntimeError("where2edit_amd ops run on the GPU only (got a CPU tensor); the CPU restatement is oracle/, for tests")
     batch, cin, height, width = input.shape
     cout, k = mod.out_channel, mod.kernel_size
     weight = mod.scale * mod.weight * style
