@@ -15,6 +15,8 @@ timeout -k 10 300 python3 bench.py --workload 3 --batch 8 --no-cpu-baseline --no
 timeout -k 10 300 python3 bench.py --workload 2 --batch 8 --no-cpu-baseline --no-preview --no-config3 --no-n1-b8 > $O/bench_line_w2_b8.json 2> $O/bench_line_w2_b8.err || true
 echo config-3 done
 timeout -k 10 200 python3 tools/layer_bench.py --warm 1.5 --iters 50 > $O/layer_bench.txt 2>&1 || true
+timeout -k 10 200 python3 tools/layer_bench.py --batch 8 --warm 1.0 --iters 30 > $O/layer_bench_b8.txt 2>&1 || true
+timeout -k 10 300 python3 bench.py --workload 5 --batch 8 > $O/bench_line_w5_b8.json 2> $O/bench_line_w5_b8.err || true
 timeout -k 10 200 python3 tools/mem_bench.py > $O/mem_bench.txt 2>&1 || true
 echo micro done
 cd /tmp
@@ -30,3 +32,11 @@ timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o fetch
 timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o write --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-n1-b8 --no-cpu-baseline --no-kernel-timing > $O/bench_write.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $(find $R/fetch -name '*counter_collection.csv' | head -1) $(find $R/write -name '*counter_collection.csv' | head -1) $TAG $O > $O/pmc.log 2>&1 || true
 echo pmc done
+# SQ counter pass (its own run: --pmc must not be combined with the tracing domains other than --kernel-trace): matrix-pipe occupancy
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/sq -o sq --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-stabilise --graph off --no-preview --no-config3 --no-n1-b8 --no-cpu-baseline --no-kernel-timing > $O/bench_sq.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/pmc_mfma.py $(find $R/sq -name '*counter_collection.csv' | head -1) > $O/pmc_mfma.txt 2>&1 || true
+echo sq done
+cd $GRAFT_REPO_ROOT
+timeout -k 10 200 python3 tools/cfg_selections.py $O/cfg_selections.txt > /dev/null 2>&1 || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/issue_probe.hip -o /tmp/issue_probe 2> /dev/null && /tmp/issue_probe > $O/issue_probe.txt 2>&1 || true
+echo extras done
