@@ -20,7 +20,7 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = "w2e::modconv_kernel<*>" if "modconv_kernel" in name else name.split("(")[0][:60]
+        key = "w2e::modconv_kernel<*>" if ("modconv_kernel" in name or "modconv_pipe_kernel" in name) else name.split("(")[0][:60]
         d[key][0] += 1
         d[key][1] += float(r["Counter_Value"])
     return d

@@ -14,7 +14,7 @@ print(f"# {path}\n# total kernel time {tot / steps / 1e6:.3f} ms/step over {step
 fam = {}
 for r in rows:
     name = r["Name"]
-    key = "w2e::modconv_kernel<*>" if "modconv_kernel" in name else name.split("(")[0][:70]
+    key = "w2e::modconv_kernel<*>" if ("modconv_kernel" in name or "modconv_pipe_kernel" in name) else name.split("(")[0][:70]
     c, t = fam.get(key, (0, 0))
     fam[key] = (c + int(r["Calls"]), t + int(r["TotalDurationNs"]))
 print("# by kernel family: ms/step, calls/step, avg us, share")
@@ -23,5 +23,5 @@ for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t / steps / 1e6:9.3f} {c / steps:8.1f} {t / c / 1e3:10.1f} {100.0 * t / tot:6.2f}%  {k}")
 print("# modconv instantiations <MODE,EPI,NOB,NPB,WO,WP,KC>")
 for r in rows:
-    if "modconv_kernel" in r["Name"]:
+    if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"]:
         print(f"{int(r['TotalDurationNs']) / steps / 1e6:9.3f} {int(r['Calls']) / steps:8.1f} {float(r['AverageNs']) / 1e3:10.1f}  {r['Name'][5:60]}")
