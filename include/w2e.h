@@ -132,6 +132,23 @@ int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_sc
                    float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
                    const float* noise_w, const float* bias, const float* dot_with, float* dot_out, void* stream);
 
+/* ---- K1w  Winograd F(2x2,3x3) form of W2E_CONV_SAME  (model.py:270-274; the same contract as w2e_modconv3x3) --------
+ *     y[b,o] = epilogue(out_scale[b,o] * A^T [ sum_i U[.,o,i] (.) V[.,i,t] ] A),   16 products per 2x2 outputs instead of 36.
+ * Three HBM-bound passes around 16 plain [N x K] x [K x T] fp32 GEMMs (T = batch * H/2 * W/2 tiles), which the caller runs with
+ * the vendor library as ONE strided-batched GEMM  M[16][N][T] = U[16][N][K] x V[16][K][T]  (row-major, fp32):
+ *   w2e_wino_weights: packed direct-form weights wp (w2e_conv_pack: any transpose / flip) -> U [16][N][K] = G W G^T; once per pack
+ *   w2e_wino_input:   x [B,K,H,W], in_scale [B,K] or NULL -> V [16][K][T] = B^T (in_scale * window) B, zero padding 1; H, W even
+ *   w2e_wino_output:  M [16][N][T], out_scale [B,N] or NULL -> y [B,N,H,W] with w2e_modconv3x3's epilogues (act: noise_w*noise +
+ *                     bias, LeakyReLU 0.2, sqrt 2; or dot_with / dot_out: dot_out[b,o] += sum_p conv_unscaled * dot_with, by fp32
+ *                     atomics -- not for "deterministic"); (H/2)*(W/2) must be a multiple of 64.
+ * V and M are 4x the input / output bytes: the form pays on the 512-channel layers at 16^2 ... 64^2 (where2edit_amd/functional.py
+ * chooses); results differ from the direct form by fp32 rounding only (both within 1e-6 relative of float64 at K = 512). */
+int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, void* stream);
+int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, void* stream);
+int w2e_wino_output(const float* m, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int act,
+                    const float* noise, const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
+                    void* stream);
+
 /* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
  *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */
 int w2e_demod_fwd(const float* s, const float* wsq, float* d, int batch, int cin, int cout, float eps, void* stream);

@@ -994,3 +994,53 @@ def test_modconv_pipelined_kernel(b, k, n, h, w, wgs, w2e_opt):
         assert_close(y, y0, 1e-6, "pipelined == standard kernel")
     y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, None, None, h, w)
     assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "same, unmodulated")
+
+
+@pytest.mark.parametrize("b,k,n,h,w", [(2, 64, 48, 16, 16), (1, 24, 40, 32, 16), (3, 512, 512, 16, 16), (2, 16, 16, 64, 32)])
+def test_modconv_winograd_form(b, k, n, h, w):
+    """K1w: the Winograd F(2x2,3x3) form of the same-resolution conv (w2e_wino_weights / _input / _output around one strided-batched
+    fp32 GEMM) against float64 convolutions, every epilogue of w2e_modconv3x3 -- plain, unmodulated, noise + bias + LeakyReLU, and
+    the input-gradient pass (transposed + flipped pack) with the fused per-channel dot -- and against the direct kernel."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K
+    g = torch.Generator().manual_seed(17 * k + n + h)
+    wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+    scale = (k * 9) ** -0.5
+    x = torch.randn(b, k, h, w, generator=g).to(DEV)
+    s_in = (torch.randn(b, k, generator=g) * 0.3 + 1).to(DEV)
+    s_out = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    wd, xd = wt.double() * scale, x.double() * s_in.double()[:, :, None, None]
+    so = s_out.double()[:, :, None, None]
+    ref = F.conv2d(xd, wd, padding=1) * so
+    fwd, bwd = K.conv_pack(wt, scale, False, False), K.conv_pack(wt, scale, True, True)
+    noise = torch.randn(1, 1, h, w, generator=g).to(DEV)
+    nw, bias = torch.randn(1, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    pre = ref + nw.double() * noise.double() + bias.double()[None, :, None, None]
+    gy = torch.randn(b, n, h, w, generator=g).to(DEV)          # the input-gradient pass: in_scale = s_out (demod), out_scale = s_in
+    xdot = torch.randn(b, k, h, w, generator=g).to(DEV)
+    graw = F.conv_transpose2d(gy.double() * so, wd, padding=1)
+    saved = K.WINOGRAD
+    try:
+        K.set_winograd(False)
+        y_direct, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
+        gx_direct, gs_direct = K._modconv_raw(K.MODE_SAME, gy, bwd, s_out, s_in, h, w, dot_with=xdot)
+        K.set_winograd(True)
+        assert K._wino_ok(x, k, n, h, w, None)
+        y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
+        assert_close(y, ref, FWD_TOL, "winograd, plain epilogue")
+        y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, None, None, h, w)
+        assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "winograd, unmodulated")
+        y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
+        assert_close(y, F.leaky_relu(pre, 0.2) * 2 ** 0.5, FWD_TOL, "winograd + act")
+        assert_close(y, y_direct, 5e-6, "winograd == direct kernel")
+        gx, gs = K._modconv_raw(K.MODE_SAME, gy, bwd, s_out, s_in, h, w, dot_with=xdot)
+        assert_close(gx, graw * s_in.double()[:, :, None, None], FWD_TOL, "winograd input gradient")
+        assert_close(gs, (graw * xdot.double()).sum((2, 3)), FWD_TOL, "winograd fused dot")
+        assert_close(gx, gx_direct, 5e-6, "input gradient: winograd == direct")
+        assert_close(gs, gs_direct, 1e-5, "fused dot: winograd == direct")
+        out = torch.full((b + 1, n, h, w), 7.0, device=DEV)      # writing into the tail rows of a larger batch
+        K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, out=out[1:])
+        assert_close(out[1:], ref, FWD_TOL, "winograd into a view")
+        assert float(out[0].min()) == 7.0 and float(out[0].max()) == 7.0
+    finally:
+        K.set_winograd(saved)

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from where2edit_amd import _lib  # noqa: E402
+from where2edit_amd import functional as K  # noqa: E402
 
 
 def one_step(workload, batch):
@@ -31,14 +32,17 @@ def one_step(workload, batch):
         os.dup2(tmp.fileno(), 2)  # the library prints with fprintf(stderr)
         try:
             _lib.set_option("tune_print", 1)
+            K.WINO_LOG = []
             coach.train_step(w, mask)
             torch.cuda.synchronize()
         finally:
             _lib.set_option("tune_print", 0)
+            wino, K.WINO_LOG = K.WINO_LOG, None
             os.dup2(saved, 2)
             os.close(saved)
         tmp.seek(0)
         lines = [ln for ln in tmp.read().decode().splitlines() if ln.startswith("modconv mode") or ln.startswith("  ")]
+    lines += wino  # (the Winograd-form layers are chosen on the Python side: functional._wino_ok)
     del coach
     torch.cuda.empty_cache()
     return lines

@@ -1084,7 +1084,9 @@ __global__ __launch_bounds__(512, 2) void modconv_pipe_kernel(ConvParams p) {
     // descriptor that changed from tile to tile would live in VGPRs)
     const i32x4 qx = raw_rsrc(p.x, (unsigned)((int64_t)p.batch * p.K * in_plane * 4));
     const i32x4 ry = raw_rsrc(p.y, (unsigned)((int64_t)p.batch * p.N * in_plane * 4));
+    bool dma_on = true;  // (tuning aid, bit 2: only the first chunk of the first tile is staged)
     auto issue_piece = [&](unsigned img_off, int k0, int stage, int i) __attribute__((always_inline)) {
+        if (!dma_on) return;
         unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * stage_floats * 4) + (unsigned)swave * 1024u));
         asm volatile("" : "+s"(lb));  // (this wave's 64 x 16 B of the first piece; opaque: see drain_item)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pipe_kernel(ConvParams p) {
     // otherwise hoists the 64 per-item plane offsets and table addresses out of the chunk loop and spills ~200 registers)
     float os_c = 0.f, bs_c = 0.f;  // the (ob, r) pair's out_scale / bias, fetched with its first item (items come in order)
     auto drain_item = [&](const f32x16 (&acc)[NOB][NPB], const Done& d, const float* tb, unsigned soff_base, unsigned pbytes, int i) __attribute__((always_inline)) {
-        if (i >= NITEM) return;
+        if (i >= NITEM || W2E_SKIP(p, 64)) return;  // (tuning aid, bit 6: no epilogue)
         const int pb = i % NPB, r = (i / NPB) % 16, ob = i / (NPB * 16);
         const int cof = ob * 32 + (r & 3) + 8 * (r >> 2);  // channel of the item relative to the wave's first (+ 4 * half)
         if (pb == 0) os_c = tb[cof], bs_c = tb[TN + cof];
@@ -1139,6 +1141,10 @@ __global__ __launch_bounds__(512, 2) void modconv_pipe_kernel(ConvParams p) {
         // the item's plane offset on the SCALAR unit, inside the statement (left to the compiler it lands on the VALU under SGPR
         // pressure, and a VALU-written SGPR costs a readfirstlane + 5 wait states in front of every store)
         unsigned soff;
+        if (W2E_SKIP(p, 1)) {  // (tuning aid, bit 0: the item's arithmetic without its store)
+            asm volatile("" ::"v"(v));
+            return;
+        }
         asm volatile("s_mul_i32 %0, %4, %5\n\ts_add_u32 %0, %0, %3\n\tbuffer_store_dword %1, %2, %6, %0 offen"
                      : "=&s"(soff)
                      : "v"(v), "v"(d.yoff[pb]), "s"(soff_base), "s"(pbytes), "n"(cof), "s"(ry)
@@ -1161,6 +1167,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pipe_kernel(ConvParams p) {
     int stage = 0;
     Done done;
     f32x16 accA[NOB][NPB], accB[NOB][NPB];
+    if (W2E_SKIP(p, 4)) dma_on = false;
 
     // one tile: accC accumulates it, accP holds the previous tile (drained during chunks 0 and 1)
     auto tile_body = [&](f32x16 (&accC)[NOB][NPB], const f32x16 (&accP)[NOB][NPB], int it) __attribute__((always_inline)) {
@@ -1183,13 +1190,20 @@ __global__ __launch_bounds__(512, 2) void modconv_pipe_kernel(ConvParams p) {
         // fly), barrier, MFMAs with `piece(g)` after every accumulator group.  The chunk flavours follow each other as straight-line
         // code (a switch on the chunk index inside one loop made the register allocator spill 150-250 registers).
         auto run_chunk = [&](int c, auto piece) __attribute__((always_inline)) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of the chunk have landed (and its epilogue stores) ...
-            __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
+            if (!W2E_SKIP(p, 8)) {                   // (tuning aid, bit 3: no wait, no barrier)
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of the chunk have landed (and its epilogue stores) ...
+                __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
+            }
             const float4* wsc = reinterpret_cast<const float4*>(smem + stage * stage_floats);
             const float4* xsc = wsc + WS_FLOATS / 4;
             float4 s4[1] = {st[c * 2 + half]};
-            mfma_chunk<W2E_CONV_SAME, NOB, NPB, KC, TN, 0, 0, true, false>(accC, wsc, xsc, a_base, base, PW, PLANE, s4,
-                                                                         [&](int) __attribute__((always_inline)) {}, piece);
+            if (W2E_SKIP(p, 2)) {  // (tuning aid, bit 1: the pieces without the MFMAs)
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) piece(g);
+            } else {
+                mfma_chunk<W2E_CONV_SAME, NOB, NPB, KC, TN, 0, 0, true, false>(accC, wsc, xsc, a_base, base, PW, PLANE, s4,
+                                                                             [&](int) __attribute__((always_inline)) {}, piece);
+            }
             stage ^= 1;
         };
         // chunks 0, 1, 2: + the previous tile's epilogue, one item per group

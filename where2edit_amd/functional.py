@@ -244,6 +244,62 @@ def conv_pack(weight, scale, transpose, flip):
 
 MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 
+# ---- Winograd F(2x2,3x3) form of the same-resolution layers (include/w2e.h, K1w): input transform -> ONE strided-batched fp32 GEMM
+# (16 x [N,K] x [K,tiles], the vendor library through torch.bmm) -> output transform with the direct kernel's epilogues.
+# "auto": where it measures faster than the direct kernel (profiles/r03_winograd.txt) -- the contraction must dominate the 4x larger
+# transform-domain tensors: K, N >= 256 at 16^2 ... 128^2 (512 -> 512 @ 64^2, batch 8: 1.05 -> 0.63 ms; 256 -> 256 @ 128^2: 1.07 -> 0.81;
+# 128 -> 128 @ 256^2: 1.10 -> 1.21, left to the direct kernel).  W2E_WINOGRAD = 0 / 1 (read once here): never / wherever the shapes allow.
+WINOGRAD = {"0": False, "1": True}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
+
+
+WINO_LOG = None  # a list: every Winograd-form conv appends one line in the format of the library's tune_print (tests, tools/cfg_selections.py)
+
+
+def set_winograd(mode):
+    """mode: "auto" | True | False"""
+    global WINOGRAD
+    if mode not in ("auto", True, False):
+        raise ValueError("set_winograd: 'auto', True or False")
+    WINOGRAD = mode
+
+
+def _wino_ok(x, k, n, h, w, dot_with):
+    if WINOGRAD is False or (h & 1) or (w & 1) or ((h >> 1) * (w >> 1)) % 64 or x.shape[0] == 0:
+        return False
+    if x.shape[0] * max(k, n) >= 65536:
+        return False
+    if WINOGRAD == "auto" and not (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128):
+        return False
+    if _lib.get_option("conv_precision") != 0 or (dot_with is not None and _lib.get_option("deterministic")):
+        return False
+    return _lib.get_option("tune_cfg") < 0  # (a forced direct tile: tests, tools/layer_bench.py)
+
+
+def _wino_weights(wp, k, n):
+    """U [16,N,K] of a packed weight, built once and kept on the pack tensor (a pack is rebuilt, not edited, when its weight changes)."""
+    u = getattr(wp, "_w2e_wino_u", None)
+    if u is None:
+        u = torch.empty((16, n, k), device=wp.device, dtype=torch.float32)
+        call("w2e_wino_weights", ptr(wp), ptr(u), k, n, stream_ptr())
+        wp._w2e_wino_u = u
+    return u
+
+
+def _modconv_wino(x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot):
+    b = x.shape[0]
+    tiles = b * (h >> 1) * (w >> 1)
+    if WINO_LOG is not None:
+        WINO_LOG.append(f"modconv mode 0 (winograd F(2x2,3x3){', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> 16 x [{n}x{k}] x [{k}x{tiles}]")
+    u = _wino_weights(wp, k, n)
+    v = torch.empty((16, k, tiles), device=x.device, dtype=torch.float32)
+    call("w2e_wino_input", ptr(x), ptr(in_scale), ptr(v), b, k, h, w, stream_ptr())
+    m = torch.bmm(u, v)  # [16, N, tiles]
+    noise = noise_w = bias = None
+    if act is not None:
+        noise, noise_w, bias = act
+    call("w2e_wino_output", ptr(m), ptr(out_scale), ptr(y), b, n, h, w, int(act is not None), ptr(noise), ptr(noise_w), ptr(bias),
+         ptr(dot_with), ptr(dot), stream_ptr())
+
 
 def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None, out=None, dot_out=None):
     """One call of w2e_modconv3x3.  h,w: input size for SAME/UP, output size for DOWN.  `out`: write into this
@@ -267,8 +323,11 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
         noise, noise_w, bias = act
     # algorithmic FLOPs: 2*K*N*9 per domain pixel (MACs actually needed; SURVEY 2.3 convention)
     sp = profiling.span("modconv3x3", 2.0 * b * k * n * 9 * h * w)
-    call("w2e_modconv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n, h, w,
-         int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
+    if mode == MODE_SAME and _wino_ok(x, k, n, h, w, dot_with):
+        _modconv_wino(x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot)
+    else:
+        call("w2e_modconv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n, h, w,
+             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
     if sp is not None:
         sp.end()
     return y, dot
