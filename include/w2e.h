@@ -132,20 +132,23 @@ int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_sc
                    float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
                    const float* noise_w, const float* bias, const float* dot_with, float* dot_out, void* stream);
 
-/* ---- K1w  Winograd F(2x2,3x3) form of W2E_CONV_SAME  (model.py:270-274; the same contract as w2e_modconv3x3) --------
- *     y[b,o] = epilogue(out_scale[b,o] * A^T [ sum_i U[.,o,i] (.) V[.,i,t] ] A),   16 products per 2x2 outputs instead of 36.
- * Three HBM-bound passes around 16 plain [N x K] x [K x T] fp32 GEMMs (T = batch * H/2 * W/2 tiles), which the caller runs with
- * the vendor library as ONE strided-batched GEMM  M[16][N][T] = U[16][N][K] x V[16][K][T]  (row-major, fp32):
- *   w2e_wino_weights: packed direct-form weights wp (w2e_conv_pack: any transpose / flip) -> U [16][N][K] = G W G^T; once per pack
- *   w2e_wino_input:   x [B,K,H,W], in_scale [B,K] or NULL -> V [16][K][T] = B^T (in_scale * window) B, zero padding 1; H, W even
- *   w2e_wino_output:  M [16][N][T], out_scale [B,N] or NULL -> y [B,N,H,W] with w2e_modconv3x3's epilogues (act: noise_w*noise +
+/* ---- K1w  Winograd forms of W2E_CONV_SAME  (model.py:270-274; the same contract as w2e_modconv3x3) ---------------------
+ *     y[b,o] = epilogue(out_scale[b,o] * A^T [ sum_i U[.,o,i] (.) V[.,i,t] ] A)
+ * m = 2: F(2x2,3x3), 16 products per 2x2 outputs instead of 36;  m = 4: F(4x4,3x3), 36 per 4x4 outputs instead of 144
+ * (interpolation points 0, +-1, +-2, inf).  P = (m+2)^2 transform-domain positions, T = batch * H/m * W/m tiles.
+ * Three HBM-bound passes around P plain [N x K] x [K x T] fp32 GEMMs, which the caller runs with the vendor library as ONE
+ * strided-batched GEMM  M[P][N][T] = U[P][N][K] x V[P][K][T]  (row-major, fp32):
+ *   w2e_wino_weights: packed direct-form weights wp (w2e_conv_pack: any transpose / flip) -> U [P][N][K] = G W G^T; once per pack
+ *   w2e_wino_input:   x [B,K,H,W], in_scale [B,K] or NULL -> V [P][K][T] = B^T (in_scale * window) B, zero padding 1; H, W % m == 0
+ *   w2e_wino_output:  M [P][N][T], out_scale [B,N] or NULL -> y [B,N,H,W] with w2e_modconv3x3's epilogues (act: noise_w*noise +
  *                     bias, LeakyReLU 0.2, sqrt 2; or dot_with / dot_out: dot_out[b,o] += sum_p conv_unscaled * dot_with, by fp32
- *                     atomics -- not for "deterministic"); (H/2)*(W/2) must be a multiple of 64.
- * V and M are 4x the input / output bytes: the form pays on the 512-channel layers at 16^2 ... 64^2 (where2edit_amd/functional.py
- * chooses); results differ from the direct form by fp32 rounding only (both within 1e-6 relative of float64 at K = 512). */
-int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, void* stream);
-int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, void* stream);
-int w2e_wino_output(const float* m, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int act,
+ *                     atomics -- not for "deterministic"); tiles per plane (H/m)*(W/m): a multiple of 64 (m = 4: or a power of two).
+ * V and M are 4x (m = 2) / 2.25x (m = 4) the input / output bytes: the forms pay where the contraction dominates that traffic
+ * (where2edit_amd/functional.py chooses per layer).  Rounding, max-norm relative to a float64 convolution at K = 128 ... 512:
+ * direct 3e-7, m = 2 6e-7, m = 4 1e-5 (its transforms multiply by up to 8 and 1/24) -- against the path's 1e-3 tolerance. */
+int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, int m, void* stream);
+int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, int m, void* stream);
+int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int m, int act,
                     const float* noise, const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
                     void* stream);
 

@@ -425,15 +425,18 @@ def test_modconv_full_size_properties(cin, cout, h, up):
     y = K.modconv(x, s, wsq, packs, blur, up)
     oh = 2 * h if up else h
     assert y.shape == (b, cout, oh, oh)
+    # (rounding-level properties: the F(4x4,3x3) form the 512-channel layer takes by default sits ~1e-5 from the exact result,
+    # the direct kernels ~3e-7 -- DESIGN.md section 4, K1w)
+    f4 = (not up) and K._wino_form(x, cin, cout, h, h, None) == 4
     y2 = K.modconv(x, 3.0 * s, wsq, packs, blur, up)                      # (1)
-    assert rel_err(y2, y) < 2e-5
+    assert rel_err(y2, y) < (1e-4 if f4 else 2e-5)
     y3 = K.modconv(-2.0 * x, s, wsq, packs, blur, up)                     # (2)
     assert rel_err(y3, -2.0 * y) < 1e-5
     xg = x.clone().requires_grad_(True)                                    # (3)
     g = torch.randn_like(y)
     (dx,) = torch.autograd.grad(K.modconv(xg, s, wsq, packs, blur, up), xg, g)
     lhs, rhs = (y.double() * g.double()).sum(), (x.double() * dx.double()).sum()
-    assert abs(lhs - rhs) <= 1e-5 * (y.double().abs() * g.double().abs()).sum()
+    assert abs(lhs - rhs) <= (5e-5 if f4 else 1e-5) * (y.double().abs() * g.double().abs()).sum()
     # (4) 8x8 output crop at an interior position against the oracle on the input crop that feeds it
     c0 = h // 2 - (h // 2) % 2
     halo = 4
@@ -996,11 +999,15 @@ def test_modconv_pipelined_kernel(b, k, n, h, w, wgs, w2e_opt):
     assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "same, unmodulated")
 
 
-@pytest.mark.parametrize("b,k,n,h,w", [(2, 64, 48, 16, 16), (1, 24, 40, 32, 16), (3, 512, 512, 16, 16), (2, 16, 16, 64, 32)])
-def test_modconv_winograd_form(b, k, n, h, w):
-    """K1w: the Winograd F(2x2,3x3) form of the same-resolution conv (w2e_wino_weights / _input / _output around one strided-batched
-    fp32 GEMM) against float64 convolutions, every epilogue of w2e_modconv3x3 -- plain, unmodulated, noise + bias + LeakyReLU, and
-    the input-gradient pass (transposed + flipped pack) with the fused per-channel dot -- and against the direct kernel."""
+@pytest.mark.parametrize("m,b,k,n,h,w", [(2, 2, 64, 48, 16, 16), (2, 1, 24, 40, 32, 16), (2, 3, 512, 512, 16, 16), (2, 2, 16, 16, 64, 32),
+                                         (4, 3, 64, 48, 16, 16), (4, 1, 24, 40, 32, 32), (4, 2, 512, 512, 32, 32), (4, 5, 16, 16, 64, 32),
+                                         (4, 2, 128, 128, 16, 32)])
+def test_modconv_winograd_form(m, b, k, n, h, w):
+    """K1w: the Winograd forms F(2x2,3x3) and F(4x4,3x3) of the same-resolution conv (w2e_wino_weights / _input / _output around one
+    strided-batched fp32 GEMM) against float64 convolutions, every epilogue of w2e_modconv3x3 -- plain, unmodulated, noise + bias +
+    LeakyReLU, and the input-gradient pass (transposed + flipped pack) with the fused per-channel dot (16 tiles per plane: the
+    segmented reduction; 64 and more: whole waves) -- and against the direct kernel.  Tolerances: FWD_TOL = 1e-4 against float64
+    for both; the measured distance is printed by -s (F(2x2): ~6e-7, F(4x4): ~1e-5 at K = 512)."""
     import torch.nn.functional as F
     from where2edit_amd import functional as K
     g = torch.Generator().manual_seed(17 * k + n + h)
@@ -1024,20 +1031,21 @@ def test_modconv_winograd_form(b, k, n, h, w):
         K.set_winograd(False)
         y_direct, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
         gx_direct, gs_direct = K._modconv_raw(K.MODE_SAME, gy, bwd, s_out, s_in, h, w, dot_with=xdot)
-        K.set_winograd(True)
-        assert K._wino_ok(x, k, n, h, w, None)
+        K.set_winograd(m)
+        assert K._wino_form(x, k, n, h, w, None) == m
         y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w)
         assert_close(y, ref, FWD_TOL, "winograd, plain epilogue")
         y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, None, None, h, w)
         assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "winograd, unmodulated")
         y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
         assert_close(y, F.leaky_relu(pre, 0.2) * 2 ** 0.5, FWD_TOL, "winograd + act")
-        assert_close(y, y_direct, 5e-6, "winograd == direct kernel")
+        assert_close(y, y_direct, 5e-6 if m == 2 else 1e-4, "winograd == direct kernel")
+        print(f"F({m}x{m},3x3) K={k}: |y - direct| / |direct| = {rel_err(y, y_direct):.2e}")
         gx, gs = K._modconv_raw(K.MODE_SAME, gy, bwd, s_out, s_in, h, w, dot_with=xdot)
         assert_close(gx, graw * s_in.double()[:, :, None, None], FWD_TOL, "winograd input gradient")
         assert_close(gs, (graw * xdot.double()).sum((2, 3)), FWD_TOL, "winograd fused dot")
-        assert_close(gx, gx_direct, 5e-6, "input gradient: winograd == direct")
-        assert_close(gs, gs_direct, 1e-5, "fused dot: winograd == direct")
+        assert_close(gx, gx_direct, 5e-6 if m == 2 else 1e-4, "input gradient: winograd == direct")
+        assert_close(gs, gs_direct, 1e-5 if m == 2 else 1e-4, "fused dot: winograd == direct")
         out = torch.full((b + 1, n, h, w), 7.0, device=DEV)      # writing into the tail rows of a larger batch
         K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, out=out[1:])
         assert_close(out[1:], ref, FWD_TOL, "winograd into a view")

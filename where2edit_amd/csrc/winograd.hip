@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) form of the same-resolution modulated 3x3 convolution (K1w, include/w2e.h) for gfx950.
+// Winograd forms -- F(2x2,3x3) and F(4x4,3x3) -- of the same-resolution modulated 3x3 convolution (K1w, include/w2e.h) for gfx950.
 //
 //   y[b,o] = out_scale[b,o] * conv3x3(W, in_scale[b,i] * x[b,i])          (model.py:270-274 in the shared-weight form of K1)
 //          = out_scale * A^T [ sum_i (G W[o,i] G^T) (.) (B^T (in_scale * d[b,i]) B) ] A     per 2x2 output tile, d = its 4x4 input window
@@ -11,7 +11,7 @@
 //                                 w2e_modconv3x3: noise + bias + LeakyReLU, and the fused per-channel dot of the input gradient
 // and the 16 GEMMs between them are plain strided-batched fp32 GEMMs (the host uses the vendor library: hipBLASLt through
 // torch.bmm; 118-135 TFLOP/s on these shapes, profiles/r03_winograd.txt).  V and M are 4x the size of the input / output, so
-// the form pays where the contraction dominates the traffic: the 512-channel layers at 16^2 ... 64^2 (functional._wino_auto).
+// the form pays where the contraction dominates the traffic (functional._wino_form); F(4x4,3x3) further down in this file.
 // fp32 throughout; rounding differs from the direct form by ~2x its own error (6e-7 vs 3e-7 relative at K = 512).
 #include "common.h"
 #include "../../include/w2e.h"
@@ -146,52 +146,225 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- F(4x4, 3x3)
+// 36 products per 4x4 outputs instead of 144 (4x fewer FLOPs), and transform-domain tensors 2.25x the input / output instead of 4x:
+// faster than F(2x2,3x3) everywhere and ahead of the direct kernel down to 128 channels at 256^2.  The price is rounding: the
+// transforms multiply by up to 8 and 1/24, and the result sits ~1e-5 (max-norm relative, K = 128 ... 512) from the float64
+// convolution where the direct form and F(2x2,3x3) sit at 3e-7 / 6e-7 -- two decades inside the path's 1e-3 tolerance (BASELINE
+// north_star), one inside the tests' 1e-4; functional.set_winograd("f2") keeps the tighter form.
+// Interpolation points 0, +-1, +-2, inf (Lavin & Gray):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ wp, float* __restrict__ u, int K, int N) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)K * N) return;
+    const int k = (int)(e % K), n = (int)(e / K);
+    const int kc = k >> 3, c = (k & 7) >> 1, h = k & 1;
+    double g[3][3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) g[tap / 3][tap % 3] = (double)wp[((((int64_t)kc * 9 + tap) * 2 + h) * N + n) * 4 + c];
+    // (in float64, rounded once: the 1/6 and 1/24 of G are not exact in binary)
+    auto row = [](double a, double b, double cc, double (&o)[6]) {
+        o[0] = a / 4.0;
+        o[1] = -(a + b + cc) / 6.0;
+        o[2] = -(a - b + cc) / 6.0;
+        o[3] = a / 24.0 + b / 12.0 + cc / 6.0;
+        o[4] = a / 24.0 - b / 12.0 + cc / 6.0;
+        o[5] = cc;
+    };
+    double t[6][3];  // G g
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double col[6];
+        row(g[0][j], g[1][j], g[2][j], col);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][j] = col[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double o[6];
+        row(t[i][0], t[i][1], t[i][2], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u[((int64_t)(i * 6 + j) * N + n) * K + k] = (float)o[j];
+    }
+}
+
+__device__ __forceinline__ void wino4_bt(const float (&d)[6], float (&t)[6]) {  // t = B^T d
+    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+// One thread per (plane (b,k), tile): the 6x6 window at (4*ty - 1, 4*tx - 1), zero outside the image.
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                          float* __restrict__ v, int B, int K, int H, int W) {
+    const int TX = W >> 2, TY = H >> 2, tiles = TX * TY;
+    const int64_t T = (int64_t)B * tiles;
+    const int plane = blockIdx.y;  // b * K + k
+    const int b = plane / K, k = plane - b * K;
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= tiles) return;
+    const int ty = tile / TX, tx = tile - ty * TX;
+    const float* xp = x + (int64_t)plane * H * W;
+    const float sc = in_scale ? in_scale[plane] : 1.f;
+    float t[6][6];  // rows transformed first: t[r][.] = B^T (row r of the window), then the columns
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int iy = 4 * ty - 1 + r;
+        const bool rin = iy >= 0 && iy < H;
+        const float* row = xp + (int64_t)(rin ? iy : 0) * W + 4 * tx;
+        const float4 mid = rin ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float d[6] = {(rin && tx > 0) ? row[-1] : 0.f, mid.x, mid.y, mid.z, mid.w, (rin && tx + 1 < TX) ? row[4] : 0.f};
+        wino4_bt(d, t[r]);
+    }
+    float* vp = v + (int64_t)k * T + (int64_t)b * tiles + tile;
+    const int64_t xi_stride = (int64_t)K * T;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j]};
+        float o[6];
+        wino4_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vp[(i * 6 + j) * xi_stride] = sc * o[i];
+    }
+}
+
+__device__ __forceinline__ void wino4_at(const float (&m)[6], float (&y)[4]) {  // y = A^T m
+    const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = m[0] + p + r;
+    y[1] = q + 2.f * s;
+    y[2] = p + 4.f * r;
+    y[3] = q + 8.f * s + m[5];
+}
+
+// One thread per (output channel n, tile t): a 4x4 block of outputs, stored as four 16-byte rows.  SEG = lanes of a wave that share
+// one (b, n) plane (min(64, tiles per plane); the host requires it to divide 64): the fused dot reduces over them.
+template <bool ACT, bool DOT>
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ m, const float* __restrict__ out_scale,
+                                                           float* __restrict__ y, int B, int N, int H, int W, int seg,
+                                                           const float* __restrict__ noise, const float* __restrict__ noise_w,
+                                                           const float* __restrict__ bias, const float* __restrict__ dot_with,
+                                                           float* __restrict__ dot_out) {
+    const int TX = W >> 2, TY = H >> 2, tiles = TX * TY;
+    const int64_t T = (int64_t)B * tiles;
+    const int n = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < T;
+    const int64_t tc = live ? t : T - 1;  // (idle lanes of the last wave keep the shuffles below well defined)
+    const int b = (int)(tc / tiles), tile = (int)(tc - (int64_t)b * tiles);
+    const int ty = tile / TX, tx = tile - ty * TX;
+    const float* mp = m + (int64_t)n * T + tc;
+    const int64_t xi_stride = (int64_t)N * T;
+    float s[4][6];  // columns transformed first: s[.][j] = A^T (column j of the 6x6 products)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float col[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = mp[(i * 6 + j) * xi_stride];
+        float o[4];
+        wino4_at(col, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+    }
+    const int64_t plane = (int64_t)b * N + n;
+    const int64_t pix = (int64_t)(4 * ty) * W + 4 * tx;
+    const float os = out_scale ? out_scale[plane] : 1.f;
+    const float nw = (ACT && noise) ? noise_w[0] : 0.f;
+    const float bs = (ACT && bias) ? bias[n] : 0.f;
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float o[4];
+        wino4_at(s[i], o);
+        if (DOT) {
+            const float4 d = *reinterpret_cast<const float4*>(dot_with + plane * H * W + pix + (int64_t)i * W);
+            part += (o[0] * d.x + o[1] * d.y) + (o[2] * d.z + o[3] * d.w);
+        }
+        float4 r = make_float4(o[0] * os, o[1] * os, o[2] * os, o[3] * os);
+        if (ACT) {
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (noise) nz = *reinterpret_cast<const float4*>(noise + pix + (int64_t)i * W);
+            r.x += nw * nz.x + bs, r.y += nw * nz.y + bs, r.z += nw * nz.z + bs, r.w += nw * nz.w + bs;
+            r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
+            r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
+        }
+        if (live) *reinterpret_cast<float4*>(y + plane * H * W + pix + (int64_t)i * W) = r;
+    }
+    if (DOT) {  // dot_out[b,n] += sum_p conv_unscaled * dot_with  (w2e.h: before out_scale)
+        if (!live) part = 0.f;
+        for (int off = seg >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (live && ((threadIdx.x & 63) & (seg - 1)) == 0) atomicAdd(dot_out + plane, part);
+    }
+}
+
 }  // namespace w2e
 
 using namespace w2e;
 
 extern "C" {
 
-int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, void* stream) {
+int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, int m, void* stream) {
     W2E_REQUIRE(wp && u, "wino_weights: null tensor");
     W2E_REQUIRE(k_ch > 0 && n_ch > 0, "wino_weights: bad dims %d %d", k_ch, n_ch);
+    W2E_REQUIRE(m == 2 || m == 4, "wino_weights: output tile %d (2 or 4)", m);
     const int64_t total = (int64_t)k_ch * n_ch;
-    wino_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, u, k_ch, n_ch);
+    if (m == 2) wino_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, u, k_ch, n_ch);
+    else wino4_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, u, k_ch, n_ch);
     W2E_LAUNCH_CHECK("wino_weights");
     return 0;
 }
 
-int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, void* stream) {
+int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, int m, void* stream) {
     W2E_REQUIRE(x && v, "wino_input: null tensor");
-    W2E_REQUIRE(batch >= 0 && k_ch > 0 && h >= 2 && w >= 2 && !(h & 1) && !(w & 1), "wino_input: bad dims (H, W must be even)");
-    W2E_REQUIRE(((uintptr_t)x & 7) == 0, "wino_input: x must be 8-byte aligned");
+    W2E_REQUIRE(m == 2 || m == 4, "wino_input: output tile %d (2 or 4)", m);
+    W2E_REQUIRE(batch >= 0 && k_ch > 0 && h >= m && w >= m && h % m == 0 && w % m == 0, "wino_input: bad dims (H, W must be multiples of %d)", m);
+    W2E_REQUIRE(((uintptr_t)x & (m == 2 ? 7 : 15)) == 0, "wino_input: x must be %d-byte aligned", 4 * m);
     if (batch == 0) return 0;
-    const int tiles = (h >> 1) * (w >> 1);
+    const int tiles = (h / m) * (w / m);
     W2E_REQUIRE((int64_t)batch * k_ch < 65536, "wino_input: more than 65535 planes");
     dim3 grid((unsigned)ceil_div(tiles, 256), (unsigned)(batch * k_ch));
-    wino_input_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, in_scale, v, batch, k_ch, h, w);
+    if (m == 2) wino_input_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, in_scale, v, batch, k_ch, h, w);
+    else wino4_input_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, in_scale, v, batch, k_ch, h, w);
     W2E_LAUNCH_CHECK("wino_input");
     return 0;
 }
 
-int w2e_wino_output(const float* m, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int act,
+int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int m, int act,
                     const float* noise, const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
                     void* stream) {
-    W2E_REQUIRE(m && y, "wino_output: null tensor");
-    W2E_REQUIRE(batch >= 0 && n_ch > 0 && n_ch < 65536 && h >= 2 && w >= 2 && !(h & 1) && !(w & 1), "wino_output: bad dims (H, W must be even)");
-    W2E_REQUIRE((((h >> 1) * (w >> 1)) & 63) == 0, "wino_output: (H/2)*(W/2) must be a multiple of 64");
+    W2E_REQUIRE(mm && y, "wino_output: null tensor");
+    W2E_REQUIRE(m == 2 || m == 4, "wino_output: output tile %d (2 or 4)", m);
+    W2E_REQUIRE(batch >= 0 && n_ch > 0 && n_ch < 65536 && h >= m && w >= m && h % m == 0 && w % m == 0,
+                "wino_output: bad dims (H, W must be multiples of %d)", m);
+    const int tiles = (h / m) * (w / m);
+    // the fused dot reduces over the lanes of a wave that share a (b, n) plane: whole waves (F(2x2)) or a power-of-two segment (F(4x4))
+    W2E_REQUIRE(m == 4 ? ((tiles & 63) == 0 || (tiles < 64 && (tiles & (tiles - 1)) == 0)) : (tiles & 63) == 0,
+                "wino_output: %d tiles per plane (a multiple of 64%s)", tiles, m == 4 ? ", or a power of two below it" : "");
     W2E_REQUIRE(!(act && dot_with), "wino_output: the activation epilogue and the fused dot exclude each other");
     W2E_REQUIRE(!dot_with || dot_out, "wino_output: dot_with without dot_out");
     W2E_REQUIRE(!noise || noise_w, "wino_output: noise without noise_w");
-    W2E_REQUIRE((((uintptr_t)y | (uintptr_t)(dot_with ? dot_with : y) | (uintptr_t)(noise ? noise : y)) & 7) == 0,
-                "wino_output: y / dot_with / noise must be 8-byte aligned");
+    W2E_REQUIRE((((uintptr_t)y | (uintptr_t)(dot_with ? dot_with : y) | (uintptr_t)(noise ? noise : y)) & (m == 2 ? 7 : 15)) == 0,
+                "wino_output: y / dot_with / noise must be %d-byte aligned", 4 * m);
     if (batch == 0) return 0;
-    const int64_t T = (int64_t)batch * (h >> 1) * (w >> 1);
+    const int64_t T = (int64_t)batch * tiles;
     dim3 grid((unsigned)ceil_div(T, 256), (unsigned)n_ch);
     hipStream_t s = (hipStream_t)stream;
-    if (act) wino_output_kernel<true, false><<<grid, 256, 0, s>>>(m, out_scale, y, batch, n_ch, h, w, noise, noise_w, bias, nullptr, nullptr);
-    else if (dot_with) wino_output_kernel<false, true><<<grid, 256, 0, s>>>(m, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, dot_with, dot_out);
-    else wino_output_kernel<false, false><<<grid, 256, 0, s>>>(m, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (m == 2) {
+        if (act) wino_output_kernel<true, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, noise, noise_w, bias, nullptr, nullptr);
+        else if (dot_with) wino_output_kernel<false, true><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, dot_with, dot_out);
+        else wino_output_kernel<false, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, nullptr, nullptr);
+    } else {
+        const int seg = tiles < 64 ? tiles : 64;
+        if (act) wino4_output_kernel<true, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, noise, noise_w, bias, nullptr, nullptr);
+        else if (dot_with) wino4_output_kernel<false, true><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, dot_with, dot_out);
+        else wino4_output_kernel<false, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     W2E_LAUNCH_CHECK("wino_output");
     return 0;
 }

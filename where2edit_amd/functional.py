@@ -244,60 +244,77 @@ def conv_pack(weight, scale, transpose, flip):
 
 MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 
-# ---- Winograd F(2x2,3x3) form of the same-resolution layers (include/w2e.h, K1w): input transform -> ONE strided-batched fp32 GEMM
-# (16 x [N,K] x [K,tiles], the vendor library through torch.bmm) -> output transform with the direct kernel's epilogues.
-# "auto": where it measures faster than the direct kernel (profiles/r03_winograd.txt) -- the contraction must dominate the 4x larger
-# transform-domain tensors: K, N >= 256 at 16^2 ... 128^2 (512 -> 512 @ 64^2, batch 8: 1.05 -> 0.63 ms; 256 -> 256 @ 128^2: 1.07 -> 0.81;
-# 128 -> 128 @ 256^2: 1.10 -> 1.21, left to the direct kernel).  W2E_WINOGRAD = 0 / 1 (read once here): never / wherever the shapes allow.
-WINOGRAD = {"0": False, "1": True}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
-
-
+# ---- Winograd forms of the same-resolution layers (include/w2e.h, K1w): input transform -> ONE strided-batched fp32 GEMM
+# (P x [N,K] x [K,tiles], the vendor library through torch.bmm; P = 16 for F(2x2,3x3), 36 for F(4x4,3x3)) -> output transform with the
+# direct kernel's epilogues.  WINOGRAD (W2E_WINOGRAD, read once here):
+#   "auto"  per layer, what measures fastest (profiles/r03_winograd.txt): F(4x4,3x3) for K, N >= 128 at 16^2 ... 256^2 -- its
+#           transform-domain tensors are 2.25x the input / output and its GEMMs a quarter of the direct FLOPs; batch 8: 512 -> 512 @ 64^2
+#           1.05 -> WINO_64 ms, 256 -> 256 @ 128^2 1.07 -> WINO_128, 128 -> 128 @ 256^2 1.10 -> WINO_256; 64 -> 64 @ 512^2 stays direct
+#           (1.16 ms against 0.64 for the GEMMs alone plus 3.5 GB of transform traffic).  Rounding ~1e-5 relative (direct: 3e-7)
+#   "f2"    F(2x2,3x3) wherever it beats the direct kernel (K, N >= 256 at 16^2 ... 128^2): rounding 6e-7, about half of "auto"'s gain
+#   False   direct kernels only ("0");  2 / 4: that form wherever the shapes allow (tests)
+WINOGRAD = {"0": False, "2": 2, "4": 4, "f2": "f2"}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
 WINO_LOG = None  # a list: every Winograd-form conv appends one line in the format of the library's tune_print (tests, tools/cfg_selections.py)
 
 
 def set_winograd(mode):
-    """mode: "auto" | True | False"""
+    """mode: "auto" | "f2" | False | 2 | 4"""
     global WINOGRAD
-    if mode not in ("auto", True, False):
-        raise ValueError("set_winograd: 'auto', True or False")
+    if mode not in ("auto", "f2", False, 2, 4):
+        raise ValueError("set_winograd: 'auto', 'f2', False, 2 or 4")
     WINOGRAD = mode
 
 
-def _wino_ok(x, k, n, h, w, dot_with):
-    if WINOGRAD is False or (h & 1) or (w & 1) or ((h >> 1) * (w >> 1)) % 64 or x.shape[0] == 0:
+def _wino_shape_ok(m, b, k, n, h, w):
+    if h % m or w % m or b == 0 or b * max(k, n) >= 65536:
         return False
-    if x.shape[0] * max(k, n) >= 65536:
-        return False
-    if WINOGRAD == "auto" and not (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128):
-        return False
+    tiles = (h // m) * (w // m)
+    return tiles % 64 == 0 or (m == 4 and tiles < 64 and tiles & (tiles - 1) == 0)
+
+
+def _wino_form(x, k, n, h, w, dot_with):
+    """0 (direct kernel), 2 or 4 (the F(m x m, 3x3) form) for one W2E_CONV_SAME call."""
+    if WINOGRAD is False:
+        return 0
+    b = x.shape[0]
+    if WINOGRAD == "auto":
+        m = 4 if (k >= 128 and n >= 128 and 16 <= h <= 256 and 16 <= w <= 256) else 0
+    elif WINOGRAD == "f2":
+        m = 2 if (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128) else 0
+    else:
+        m = WINOGRAD
+    if not m or not _wino_shape_ok(m, b, k, n, h, w):
+        return 0
     if _lib.get_option("conv_precision") != 0 or (dot_with is not None and _lib.get_option("deterministic")):
-        return False
-    return _lib.get_option("tune_cfg") < 0  # (a forced direct tile: tests, tools/layer_bench.py)
+        return 0
+    return m if _lib.get_option("tune_cfg") < 0 else 0  # (a forced direct tile: tests, tools/layer_bench.py)
 
 
-def _wino_weights(wp, k, n):
-    """U [16,N,K] of a packed weight, built once and kept on the pack tensor (a pack is rebuilt, not edited, when its weight changes)."""
-    u = getattr(wp, "_w2e_wino_u", None)
+def _wino_weights(wp, k, n, m):
+    """U [(m+2)^2,N,K] of a packed weight, built once and kept on the pack tensor (a pack is rebuilt, not edited, when its weight changes)."""
+    key = "_w2e_wino_u%d" % m
+    u = getattr(wp, key, None)
     if u is None:
-        u = torch.empty((16, n, k), device=wp.device, dtype=torch.float32)
-        call("w2e_wino_weights", ptr(wp), ptr(u), k, n, stream_ptr())
-        wp._w2e_wino_u = u
+        u = torch.empty(((m + 2) ** 2, n, k), device=wp.device, dtype=torch.float32)
+        call("w2e_wino_weights", ptr(wp), ptr(u), k, n, m, stream_ptr())
+        setattr(wp, key, u)
     return u
 
 
-def _modconv_wino(x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot):
+def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot):
     b = x.shape[0]
-    tiles = b * (h >> 1) * (w >> 1)
+    tiles = b * (h // m) * (w // m)
     if WINO_LOG is not None:
-        WINO_LOG.append(f"modconv mode 0 (winograd F(2x2,3x3){', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> 16 x [{n}x{k}] x [{k}x{tiles}]")
-    u = _wino_weights(wp, k, n)
-    v = torch.empty((16, k, tiles), device=x.device, dtype=torch.float32)
-    call("w2e_wino_input", ptr(x), ptr(in_scale), ptr(v), b, k, h, w, stream_ptr())
-    m = torch.bmm(u, v)  # [16, N, tiles]
+        WINO_LOG.append(f"modconv mode 0 (winograd F({m}x{m},3x3){', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
+                        f"{(m + 2) ** 2} x [{n}x{k}] x [{k}x{tiles}]")
+    u = _wino_weights(wp, k, n, m)
+    v = torch.empty(((m + 2) ** 2, k, tiles), device=x.device, dtype=torch.float32)
+    call("w2e_wino_input", ptr(x), ptr(in_scale), ptr(v), b, k, h, w, m, stream_ptr())
+    prod = torch.bmm(u, v)  # [P, N, tiles]
     noise = noise_w = bias = None
     if act is not None:
         noise, noise_w, bias = act
-    call("w2e_wino_output", ptr(m), ptr(out_scale), ptr(y), b, n, h, w, int(act is not None), ptr(noise), ptr(noise_w), ptr(bias),
+    call("w2e_wino_output", ptr(prod), ptr(out_scale), ptr(y), b, n, h, w, m, int(act is not None), ptr(noise), ptr(noise_w), ptr(bias),
          ptr(dot_with), ptr(dot), stream_ptr())
 
 
@@ -323,8 +340,9 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
         noise, noise_w, bias = act
     # algorithmic FLOPs: 2*K*N*9 per domain pixel (MACs actually needed; SURVEY 2.3 convention)
     sp = profiling.span("modconv3x3", 2.0 * b * k * n * 9 * h * w)
-    if mode == MODE_SAME and _wino_ok(x, k, n, h, w, dot_with):
-        _modconv_wino(x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot)
+    form = _wino_form(x, k, n, h, w, dot_with) if mode == MODE_SAME else 0
+    if form:
+        _modconv_wino(form, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot)
     else:
         call("w2e_modconv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n, h, w,
              int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
