@@ -20,7 +20,12 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        key = "w2e::modconv_kernel<*>" if ("modconv_kernel" in name or "modconv_pipe_kernel" in name) else name.split("(")[0][:60]
+        if "modconv_kernel" in name or "modconv_pipe_kernel" in name:
+            key = "w2e::modconv_kernel<*>"
+        elif name.startswith("Cijk_"):
+            key = "Cijk_* (library fp32 GEMMs: the Winograd-domain contraction; a few small stock-op GEMMs)"
+        else:
+            key = name.split("(")[0][:60]
         d[key][0] += 1
         d[key][1] += float(r["Counter_Value"])
     return d
@@ -36,6 +41,14 @@ def main():
              "# uncalibrated: its corrected figure is an upper bound, the uncorrected one a lower bound.",
              "# kernel, launches, FETCH_SIZE KB/launch, WRITE_SIZE KB/launch, HBM MB/launch corrected, uncorrected"]
     out = {}
+    # every 3x3 modulated conv call of the step = a direct launch, or a Winograd-form call (one wino*_output launch each, with its
+    # input transform and its GEMM): the `traffic` of bench.py's roofline is their HBM bytes per call
+    conv = [k for k in f if k in w and ("modconv_kernel" in k or "wino" in k or k.startswith("Cijk_"))]
+    calls = sum(f[k][0] for k in conv if "modconv_kernel" in k or "_output_kernel" in k)
+    if calls:
+        ft, wt = sum(f[k][1] for k in conv) / calls, sum(w[k][1] for k in conv) / calls
+        lines.append(f"all 3x3 modulated conv calls (direct launches + Winograd-form calls), {calls}, {ft:.0f}, {wt:.0f}, {(2 * ft + wt) / 1024:.1f}, {(ft + wt) / 1024:.1f}")
+        out["conv_calls"] = (2 * ft + wt) * 1024
     for k in sorted(f, key=lambda k: -f[k][1]):
         if k not in w:
             continue
@@ -48,7 +61,7 @@ def main():
     out_dir = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles")
     txt = os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.txt")
     open(txt, "w").write("\n".join(lines) + "\n")
-    json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.txt", "modconv_hbm_bytes_per_launch": out["w2e::modconv_kernel<*>"]},
+    json.dump({"source": f"profiles/{tag}_pmc_hbm_traffic.txt", "modconv_hbm_bytes_per_launch": out.get("conv_calls", out.get("w2e::modconv_kernel<*>"))},
               open(os.path.join(out_dir, "traffic.json"), "w"))
     print("\n".join(lines))
 

@@ -14,9 +14,19 @@ print(f"# {path}\n# total kernel time {tot / steps / 1e6:.3f} ms/step over {step
 fam = {}
 for r in rows:
     name = r["Name"]
-    key = "w2e::modconv_kernel<*>" if ("modconv_kernel" in name or "modconv_pipe_kernel" in name) else name.split("(")[0][:70]
+    key = ("w2e::modconv_kernel<*>" if ("modconv_kernel" in name or "modconv_pipe_kernel" in name)
+           else "Cijk_* (library fp32 GEMMs)" if name.startswith("Cijk_") else name.split("(")[0][:70])
     c, t = fam.get(key, (0, 0))
     fam[key] = (c + int(r["Calls"]), t + int(r["TotalDurationNs"]))
+# the 3x3 modulated convs as bench.py's roofline counts them: direct launches + Winograd-form calls (input transform + the
+# library's strided-batched GEMM + output transform; the Cijk_* rows also hold a few small stock-op GEMMs, < 0.06 ms per step)
+conv_t = sum(int(r["TotalDurationNs"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"]
+             or "wino" in r["Name"] or r["Name"].startswith("Cijk_"))
+conv_c = sum(int(r["Calls"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"] or "_output_kernel" in r["Name"])
+wino_t = sum(int(r["TotalDurationNs"]) for r in rows if "wino" in r["Name"] or r["Name"].startswith("Cijk_"))
+if conv_c:
+    print(f"# all 3x3 modulated conv calls: {conv_t / steps / 1e6:.3f} ms/step, {conv_c / steps:.1f} calls/step, {conv_t / conv_c / 1e3:.1f} us per call "
+          f"(of which Winograd-form calls: {wino_t / steps / 1e6:.3f} ms/step)")
 print("# by kernel family: ms/step, calls/step, avg us, share")
 top = 18 if "--all" not in sys.argv else len(fam)  # --all: every kernel family (the launch tail)
 for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:

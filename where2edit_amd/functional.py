@@ -339,8 +339,8 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
     if act is not None:
         noise, noise_w, bias = act
     # algorithmic FLOPs: 2*K*N*9 per domain pixel (MACs actually needed; SURVEY 2.3 convention)
-    sp = profiling.span("modconv3x3", 2.0 * b * k * n * 9 * h * w)
     form = _wino_form(x, k, n, h, w, dot_with) if mode == MODE_SAME else 0
+    sp = profiling.span("modconv3x3_wino%d" % form if form else "modconv3x3", 2.0 * b * k * n * 9 * h * w)
     if form:
         _modconv_wino(form, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot)
     else:
