@@ -140,17 +140,18 @@ int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_sc
  * strided-batched GEMM  M[P][N][T] = U[P][N][K] x V[P][K][T]  (row-major, fp32):
  *   w2e_wino_weights: packed direct-form weights wp (w2e_conv_pack: any transpose / flip) -> U [P][N][K] = G W G^T; once per pack
  *   w2e_wino_input:   x [B,K,H,W], in_scale [B,K] or NULL -> V [P][K][T] = B^T (in_scale * window) B, zero padding 1; H, W % m == 0
- *   w2e_wino_output:  M [P][N][T], out_scale [B,N] or NULL -> y [B,N,H,W] with w2e_modconv3x3's epilogues (act: noise_w*noise +
- *                     bias, LeakyReLU 0.2, sqrt 2; or dot_with / dot_out: dot_out[b,o] += sum_p conv_unscaled * dot_with, by fp32
- *                     atomics -- not for "deterministic"); tiles per plane (H/m)*(W/m): a multiple of 64 (m = 4: or a power of two).
+ *   w2e_wino_output:  M [P][N][T], out_scale [B,N] or NULL -> y [B,N,H,W] with the epilogues of w2e_modconv3x3 (act = 1:
+ *                     noise_w*noise + bias, LeakyReLU 0.2, sqrt 2; or dot_with / dot_out: dot_out[b,o] += sum_p conv_unscaled *
+ *                     dot_with, by fp32 atomics -- not for "deterministic" -- with (H/m)*(W/m) tiles per plane a multiple of 64,
+ *                     for m = 4 also a power of two below it) and of w2e_conv3x3 (act = 2: + bias[o], PReLU(slope[o]) if slope).
  * V and M are 4x (m = 2) / 2.25x (m = 4) the input / output bytes: the forms pay where the contraction dominates that traffic
  * (where2edit_amd/functional.py chooses per layer).  Rounding, max-norm relative to a float64 convolution at K = 128 ... 512:
  * direct 3e-7, m = 2 6e-7, m = 4 1e-5 (its transforms multiply by up to 8 and 1/24) -- against the path's 1e-3 tolerance. */
 int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, int m, void* stream);
 int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, int m, void* stream);
 int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int m, int act,
-                    const float* noise, const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
-                    void* stream);
+                    const float* noise, const float* noise_w, const float* bias, const float* slope, const float* dot_with,
+                    float* dot_out, void* stream);
 
 /* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
  *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */

@@ -235,3 +235,32 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
     rep = run(img.to(DEV), text.to(DEV), att_text.to(DEV))
     for key in ("latents", "img_orig", "mask", "img_gen", "features_gen"):
         assert_close(rep[key], out[key], 1e-5, f"graph replay: {key}")  # (split-K joins by fp32 atomics: run-to-run rounding)
+
+
+@pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 128, 28, 28), (2, 2, 256, 256, 14, 14), (4, 1, 64, 64, 112, 112), (2, 5, 128, 64, 14, 28)])
+def test_conv3x3_winograd_forms(m, b, k, n, h, w):
+    """The stride-1 convs of the IR-SE50 / e4e encoders through the Winograd forms (w2e_wino_input / one strided-batched GEMM /
+    w2e_wino_output with the bias + PReLU epilogue of w2e_conv3x3): forward with BN scale, bias and PReLU, the input-gradient form
+    (in_scale on the transposed + flipped pack), against float64 and against the direct kernel; tile counts that are no multiple
+    of 64 (196, 49 per image)."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K, irse_hip as I
+    g = torch.Generator().manual_seed(5 * k + n + h)
+    wt = (torch.randn(n, k, 3, 3, generator=g) * (k * 9) ** -0.5).to(DEV)
+    x = torch.randn(b, k, h, w, generator=g).to(DEV)
+    a = (torch.rand(b, n, generator=g) + 0.5).to(DEV)
+    bias, slope = torch.randn(n, generator=g).to(DEV), (torch.rand(n, generator=g) * 0.5 + 0.05).to(DEV)
+    fwd, bwd = K.conv_pack(wt, 1.0, False, False), K.conv_pack(wt, 1.0, True, True)
+    pre = F.conv2d(x.double(), wt.double(), padding=1) * a.double()[:, :, None, None] + bias.double()[None, :, None, None]
+    ref = torch.where(pre > 0, pre, pre * slope.double()[None, :, None, None])
+    y0 = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, slope=slope, form=0)
+    y = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, slope=slope, form=m)
+    assert_close(y, ref, 1e-4, "winograd conv + BN + PReLU"), assert_close(y, y0, 1e-4, "winograd == direct")
+    y = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, form=m)
+    assert_close(y, pre, 1e-4, "winograd conv + BN (no PReLU)")
+    gy = torch.randn(b, n, h, w, generator=g).to(DEV)
+    gx = I.conv3x3(gy, bwd, k, h, w, in_scale=a, form=m)
+    assert_close(gx, F.conv_transpose2d(gy.double() * a.double()[:, :, None, None], wt.double(), padding=1), 1e-4, "winograd input gradient")
+    out = torch.zeros(b + 2, k, h, w, device=DEV)
+    I.conv3x3(gy, bwd, k, h, w, in_scale=a, out=out[:b], form=m)
+    assert torch.equal(out[:b], gx) and float(out[b:].abs().max()) == 0.0

@@ -14,26 +14,36 @@ def timeit(fn, iters=30):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
-shapes = [(16, 64, 56), (16, 128, 28), (16, 256, 14), (16, 512, 7), (8, 256, 14), (8, 256, 32), (8, 512, 16)]
-for B, C, H in shapes:
-    w = torch.randn(C, C, 3, 3, device="cuda")
+# (batch, cin, cout, size): IR-SE50 at 112^2 (id loss: batch 16 = 8 generated + 8 originals; its backward: batch 8) and at 256^2 (e4e, batch 8)
+shapes = [(16, 64, 64, 112), (16, 64, 64, 56), (16, 64, 128, 56), (16, 128, 128, 28), (16, 128, 256, 28), (16, 256, 256, 14), (16, 256, 512, 14),
+          (16, 512, 512, 7), (8, 64, 64, 56), (8, 128, 128, 28), (8, 256, 256, 14),
+          (8, 64, 64, 256), (8, 64, 64, 128), (8, 64, 128, 128), (8, 128, 128, 64), (8, 128, 256, 64), (8, 256, 256, 32), (8, 256, 512, 32), (8, 512, 512, 16)]
+sweep = "--sweep" in sys.argv  # also the exhaustive tile / split-K sweep of the direct kernel (slow)
+for B, Ci, C, H in shapes:
+    w = torch.randn(C, Ci, 3, 3, device="cuda")
     wp = K.conv_pack(w, 1.0, False, False)
-    x = torch.randn(B, C, H, H, device="cuda")
+    x = torch.randn(B, Ci, H, H, device="cuda")
     bias, slope = torch.randn(C, device="cuda"), torch.rand(C, device="cuda")
-    flop = 2.0 * B * C * C * 9 * H * H
+    flop = 2.0 * B * C * Ci * 9 * H * H
     res = []
-    for prelu in (True, False):
-        base = timeit(lambda: I.conv3x3(x, wp, C, H, H, bias=bias if prelu else None, slope=slope if prelu else None))
-        res.append(f"{'prelu' if prelu else 'plain'} auto {base:6.1f}us ({flop / base / 1e6:5.1f} TF/s)")
+    run = lambda form: I.conv3x3(x, wp, C, H, H, bias=bias, slope=slope, form=form)
+    base = timeit(lambda: run(0))
+    res.append(f"direct {base:6.1f}us ({flop / base / 1e6:5.1f} TF/s)")
+    for m in (2, 4):
+        if H % m == 0:
+            t = timeit(lambda: run(m))
+            res.append(f"F({m}x{m}) {t:6.1f}us ({flop / t / 1e6:5.1f})")
+    res.append(f"chosen: {I._wino_form(B, Ci, C, H, H) or 'direct'}")
+    if sweep:
         best = (1e9, None)
         for cfg in range(0, 11):
             for sp in (1, 2, 4, 8):
                 _lib.set_option("tune_cfg", f"{cfg},{sp},0")
                 try:
-                    t = timeit(lambda: I.conv3x3(x, wp, C, H, H, bias=bias if prelu else None, slope=slope if prelu else None), 10)
+                    t = timeit(lambda: run(0), 10)
                 except RuntimeError:
                     continue
                 if t < best[0]: best = (t, (cfg, sp))
         _lib.set_option("tune_cfg", "")
-        res.append(f"best cfg {best[1]} {best[0]:6.1f}us ({flop / best[0] / 1e6:5.1f} TF/s)")
-    print(f"B{B} C{C} {H}x{H} {flop/1e9:5.2f} GF: " + " | ".join(res), flush=True)
+        res.append(f"best direct cfg {best[1]} {best[0]:6.1f}us ({flop / best[0] / 1e6:5.1f} TF/s)")
+    print(f"B{B} {Ci}->{C} {H}x{H} {flop/1e9:6.2f} GF: " + " | ".join(res), flush=True)

@@ -89,17 +89,18 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 
 // One thread per (output channel n, tile t).  A wave's 64 tiles belong to one (b, n) plane (the host requires tiles % 64 == 0),
 // so the fused dot is a wave reduction and one atomic per wave.
-template <bool ACT, bool DOT>
+// ACT: 0 none; 1 = + noise_w*noise + bias, LeakyReLU(0.2) * sqrt 2 (StyledConv); 2 = + bias, PReLU(slope[n]) when slope != NULL (IR-SE50).
+template <int ACT, bool DOT>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ out_scale,
                                                           float* __restrict__ y, int B, int N, int H, int W,
                                                           const float* __restrict__ noise, const float* __restrict__ noise_w,
-                                                          const float* __restrict__ bias, const float* __restrict__ dot_with,
-                                                          float* __restrict__ dot_out) {
+                                                          const float* __restrict__ bias, const float* __restrict__ slope,
+                                                          const float* __restrict__ dot_with, float* __restrict__ dot_out) {
     const int TX = W >> 1, TY = H >> 1, tiles = TX * TY;
     const int64_t T = (int64_t)B * tiles;
     const int n = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;  // (whole waves: T % 64 == 0)
+    if (t >= T) return;  // (with the fused dot: whole waves, T % 64 == 0)
     const int b = (int)(t / tiles), tile = (int)(t - (int64_t)b * tiles);
     const int ty = tile / TX, tx = tile - ty * TX;
     const float* mp = m + (int64_t)n * T + t;
@@ -134,13 +135,21 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float v0 = o[i][0] * os, v1 = o[i][1] * os;
-        if (ACT) {
+        if (ACT == 1) {
             const float nw = noise ? noise_w[0] : 0.f;
             const float bs = bias ? bias[n] : 0.f;
             float2 nz = make_float2(0.f, 0.f);
             if (noise) nz = *reinterpret_cast<const float2*>(noise + pix + (int64_t)i * W);
             v0 += nw * nz.x + bs, v1 += nw * nz.y + bs;
             v0 = fmaxf(v0, 0.2f * v0) * 1.4142135623730951f, v1 = fmaxf(v1, 0.2f * v1) * 1.4142135623730951f;
+        }
+        if (ACT == 2) {
+            const float bs = bias ? bias[n] : 0.f;
+            v0 += bs, v1 += bs;
+            if (slope) {
+                const float sl = slope[n];
+                v0 = v0 > 0.f ? v0 : sl * v0, v1 = v1 > 0.f ? v1 : sl * v1;
+            }
         }
         *reinterpret_cast<float2*>(y + plane * H * W + pix + (int64_t)i * W) = make_float2(v0, v1);
     }
@@ -245,12 +254,12 @@ __device__ __forceinline__ void wino4_at(const float (&m)[6], float (&y)[4]) {  
 
 // One thread per (output channel n, tile t): a 4x4 block of outputs, stored as four 16-byte rows.  SEG = lanes of a wave that share
 // one (b, n) plane (min(64, tiles per plane); the host requires it to divide 64): the fused dot reduces over them.
-template <bool ACT, bool DOT>
+template <int ACT, bool DOT>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ m, const float* __restrict__ out_scale,
                                                            float* __restrict__ y, int B, int N, int H, int W, int seg,
                                                            const float* __restrict__ noise, const float* __restrict__ noise_w,
-                                                           const float* __restrict__ bias, const float* __restrict__ dot_with,
-                                                           float* __restrict__ dot_out) {
+                                                           const float* __restrict__ bias, const float* __restrict__ slope,
+                                                           const float* __restrict__ dot_with, float* __restrict__ dot_out) {
     const int TX = W >> 2, TY = H >> 2, tiles = TX * TY;
     const int64_t T = (int64_t)B * tiles;
     const int n = blockIdx.y;
@@ -275,8 +284,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const int64_t plane = (int64_t)b * N + n;
     const int64_t pix = (int64_t)(4 * ty) * W + 4 * tx;
     const float os = out_scale ? out_scale[plane] : 1.f;
-    const float nw = (ACT && noise) ? noise_w[0] : 0.f;
+    const float nw = (ACT == 1 && noise) ? noise_w[0] : 0.f;
     const float bs = (ACT && bias) ? bias[n] : 0.f;
+    const float sl = (ACT == 2 && slope) ? slope[n] : 1.f;
     float part = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -287,12 +297,17 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
             part += (o[0] * d.x + o[1] * d.y) + (o[2] * d.z + o[3] * d.w);
         }
         float4 r = make_float4(o[0] * os, o[1] * os, o[2] * os, o[3] * os);
-        if (ACT) {
+        if (ACT == 1) {
             float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
             if (noise) nz = *reinterpret_cast<const float4*>(noise + pix + (int64_t)i * W);
             r.x += nw * nz.x + bs, r.y += nw * nz.y + bs, r.z += nw * nz.z + bs, r.w += nw * nz.w + bs;
             r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
             r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
+        }
+        if (ACT == 2) {
+            r.x += bs, r.y += bs, r.z += bs, r.w += bs;
+            r.x = r.x > 0.f ? r.x : sl * r.x, r.y = r.y > 0.f ? r.y : sl * r.y;
+            r.z = r.z > 0.f ? r.z : sl * r.z, r.w = r.w > 0.f ? r.w : sl * r.w;
         }
         if (live) *reinterpret_cast<float4*>(y + plane * H * W + pix + (int64_t)i * W) = r;
     }
@@ -336,19 +351,22 @@ int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, i
 }
 
 int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int m, int act,
-                    const float* noise, const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
-                    void* stream) {
+                    const float* noise, const float* noise_w, const float* bias, const float* slope, const float* dot_with,
+                    float* dot_out, void* stream) {
     W2E_REQUIRE(mm && y, "wino_output: null tensor");
     W2E_REQUIRE(m == 2 || m == 4, "wino_output: output tile %d (2 or 4)", m);
+    W2E_REQUIRE(act >= 0 && act <= 2, "wino_output: epilogue %d (0 none, 1 StyledConv, 2 bias + PReLU)", act);
     W2E_REQUIRE(batch >= 0 && n_ch > 0 && n_ch < 65536 && h >= m && w >= m && h % m == 0 && w % m == 0,
                 "wino_output: bad dims (H, W must be multiples of %d)", m);
     const int tiles = (h / m) * (w / m);
     // the fused dot reduces over the lanes of a wave that share a (b, n) plane: whole waves (F(2x2)) or a power-of-two segment (F(4x4))
-    W2E_REQUIRE(m == 4 ? ((tiles & 63) == 0 || (tiles < 64 && (tiles & (tiles - 1)) == 0)) : (tiles & 63) == 0,
-                "wino_output: %d tiles per plane (a multiple of 64%s)", tiles, m == 4 ? ", or a power of two below it" : "");
-    W2E_REQUIRE(!(act && dot_with), "wino_output: the activation epilogue and the fused dot exclude each other");
+    W2E_REQUIRE(!dot_with || (m == 4 ? ((tiles & 63) == 0 || (tiles < 64 && (tiles & (tiles - 1)) == 0)) : (tiles & 63) == 0),
+                "wino_output: fused dot with %d tiles per plane (a multiple of 64%s)", tiles, m == 4 ? ", or a power of two below it" : "");
+    W2E_REQUIRE(!(act && dot_with), "wino_output: the activation epilogues and the fused dot exclude each other");
     W2E_REQUIRE(!dot_with || dot_out, "wino_output: dot_with without dot_out");
     W2E_REQUIRE(!noise || noise_w, "wino_output: noise without noise_w");
+    W2E_REQUIRE(act == 1 || !noise, "wino_output: noise belongs to epilogue 1");
+    W2E_REQUIRE(act == 2 || !slope, "wino_output: slope belongs to epilogue 2");
     W2E_REQUIRE((((uintptr_t)y | (uintptr_t)(dot_with ? dot_with : y) | (uintptr_t)(noise ? noise : y)) & (m == 2 ? 7 : 15)) == 0,
                 "wino_output: y / dot_with / noise must be %d-byte aligned", 4 * m);
     if (batch == 0) return 0;
@@ -356,14 +374,16 @@ int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch
     dim3 grid((unsigned)ceil_div(T, 256), (unsigned)n_ch);
     hipStream_t s = (hipStream_t)stream;
     if (m == 2) {
-        if (act) wino_output_kernel<true, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, noise, noise_w, bias, nullptr, nullptr);
-        else if (dot_with) wino_output_kernel<false, true><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, dot_with, dot_out);
-        else wino_output_kernel<false, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (act == 1) wino_output_kernel<1, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, noise, noise_w, bias, nullptr, nullptr, nullptr);
+        else if (act == 2) wino_output_kernel<2, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, bias, slope, nullptr, nullptr);
+        else if (dot_with) wino_output_kernel<0, true><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, nullptr, dot_with, dot_out);
+        else wino_output_kernel<0, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     } else {
         const int seg = tiles < 64 ? tiles : 64;
-        if (act) wino4_output_kernel<true, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, noise, noise_w, bias, nullptr, nullptr);
-        else if (dot_with) wino4_output_kernel<false, true><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, dot_with, dot_out);
-        else wino4_output_kernel<false, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (act == 1) wino4_output_kernel<1, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, noise, noise_w, bias, nullptr, nullptr, nullptr);
+        else if (act == 2) wino4_output_kernel<2, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, bias, slope, nullptr, nullptr);
+        else if (dot_with) wino4_output_kernel<0, true><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, nullptr, dot_with, dot_out);
+        else wino4_output_kernel<0, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     W2E_LAUNCH_CHECK("wino_output");
     return 0;

@@ -265,11 +265,11 @@ def set_winograd(mode):
     WINOGRAD = mode
 
 
-def _wino_shape_ok(m, b, k, n, h, w):
+def _wino_shape_ok(m, b, k, n, h, w, dot=True):
     if h % m or w % m or b == 0 or b * max(k, n) >= 65536:
         return False
-    tiles = (h // m) * (w // m)
-    return tiles % 64 == 0 or (m == 4 and tiles < 64 and tiles & (tiles - 1) == 0)
+    tiles = (h // m) * (w // m)  # (the fused dot reduces over the lanes of a wave that share a plane)
+    return (not dot) or tiles % 64 == 0 or (m == 4 and tiles < 64 and tiles & (tiles - 1) == 0)
 
 
 def _wino_form(x, k, n, h, w, dot_with):
@@ -283,7 +283,7 @@ def _wino_form(x, k, n, h, w, dot_with):
         m = 2 if (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128) else 0
     else:
         m = WINOGRAD
-    if not m or not _wino_shape_ok(m, b, k, n, h, w):
+    if not m or not _wino_shape_ok(m, b, k, n, h, w, dot_with is not None):
         return 0
     if _lib.get_option("conv_precision") != 0 or (dot_with is not None and _lib.get_option("deterministic")):
         return 0
@@ -315,7 +315,7 @@ def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, d
     if act is not None:
         noise, noise_w, bias = act
     call("w2e_wino_output", ptr(prod), ptr(out_scale), ptr(y), b, n, h, w, m, int(act is not None), ptr(noise), ptr(noise_w), ptr(bias),
-         ptr(dot_with), ptr(dot), stream_ptr())
+         None, ptr(dot_with), ptr(dot), stream_ptr())
 
 
 def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None, out=None, dot_out=None):

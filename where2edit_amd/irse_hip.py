@@ -8,6 +8,7 @@ the identity loss needs (the gradient flows back to the generated image).  One a
 import torch
 from torch.autograd.function import once_differentiable
 
+from . import _lib
 from . import functional as K
 from ._lib import call, ptr, stream_ptr
 
@@ -36,10 +37,50 @@ def declare(lib):
 
 
 # ---------------------------------------------------------------------------------------------- raw kernel calls
-def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None, out=None):
+def _wino_form(b, k, n, h, w):
+    """The Winograd form (functional.py, K1w) of one stride-1 3x3 conv of the IR-SE50 / e4e encoders, or 0: F(4x4,3x3) where the
+    image divides into 4x4 tiles, F(2x2,3x3) for the 14^2 stages, the direct kernel for the 64-channel stages, for odd sizes (7^2) and
+    where the transform-domain GEMMs are too small to pay for three launches (profiles/r03_irse_shapes.txt)."""
+    if K.WINOGRAD is False or K.WINOGRAD == "f2" and (h % 2 or w % 2):
+        return 0
+    if K.WINOGRAD in (2, 4):
+        m = K.WINOGRAD
+    elif K.WINOGRAD == "f2":
+        m = 2
+    else:
+        m = 4 if (h % 4 == 0 and w % 4 == 0) else 2
+    # measured (profiles/r03_irse_shapes.txt): the forms win from 128 channels on one side and ~3 GFLOP of direct work per call
+    # (below it three launches cost more than the GEMM saves); the library's GEMM for F(2x2) at 256 -> 512 @ 14^2 is the exception
+    if K.WINOGRAD in ("auto", "f2") and not (k >= 64 and max(k, n) >= 128 and 18.0 * b * k * n * h * w >= 3e9 and (m == 4 or n <= 256)):
+        return 0
+    if not K._wino_shape_ok(m, b, k, n, h, w, dot=False):
+        return 0
+    if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0:
+        return 0
+    return m
+
+
+def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None, out=None, form=None):
     """w2e_conv3x3.  h,w: input size for SAME / UP, output size for DOWN.  in_scale [B,K] / out_scale [B,N] / bias, slope [N].
-    `out`: a contiguous [B,n_out,h,w] tensor to write (SAME / DOWN)."""
+    `out`: a contiguous [B,n_out,h,w] tensor to write (SAME / DOWN).  `form`: None = the library's / _wino_form's choice;
+    0 / 2 / 4 force the direct kernel / a Winograd form (tools/irse_shapes.py)."""
     b, k = x.shape[0], x.shape[1]
+    if mode == K.MODE_SAME and b > 0:
+        m = _wino_form(b, k, n_out, h, w) if form is None else form
+        if m:
+            y = out if out is not None else torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
+            if out is not None:
+                assert out.shape == (b, n_out, h, w) and out.is_contiguous()
+            tiles = b * (h // m) * (w // m)
+            if K.WINO_LOG is not None:
+                K.WINO_LOG.append(f"conv3x3 (winograd F({m}x{m},3x3)) K {k} N {n_out} {h}x{w} B {b} -> {(m + 2) ** 2} x [{n_out}x{k}] x [{k}x{tiles}]")
+            u = K._wino_weights(wp, k, n_out, m)
+            v = torch.empty(((m + 2) ** 2, k, tiles), device=x.device, dtype=torch.float32)
+            call("w2e_wino_input", ptr(x), ptr(in_scale), ptr(v), b, k, h, w, m, stream_ptr())
+            prod = torch.bmm(u, v)
+            call("w2e_wino_output", ptr(prod), ptr(out_scale), ptr(y), b, n_out, h, w, m, 2 if (bias is not None or slope is not None) else 0,
+                 None, None, ptr(bias), ptr(slope), None, None, stream_ptr())
+            return y
     if out is not None:
         assert mode != K.MODE_UP and out.shape == (b, n_out, h, w) and out.is_contiguous()
         y = out
