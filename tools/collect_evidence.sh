@@ -37,6 +37,14 @@ timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUS
 python3 $GRAFT_REPO_ROOT/tools/pmc_mfma.py $(find $R/sq -name '*counter_collection.csv' | head -1) > $O/pmc_mfma.txt 2>&1 || true
 echo sq done
 cd $GRAFT_REPO_ROOT
+# the Winograd forms against the direct kernels, layer by layer (same-resolution layers; batch 8 = the merged forward, batch 4 = the backward)
+for wg in 0 f2 auto; do for bb in 8 4; do
+echo "== W2E_WINOGRAD=$wg, batch $bb" >> $O/winograd.txt
+W2E_WINOGRAD=$wg timeout -k 10 200 python3 tools/layer_bench.py --batch $bb --warm 1.0 --iters 20 2>&1 | grep "layer\|same\|total" >> $O/winograd.txt || true
+done; done
+timeout -k 10 300 python3 tools/irse_shapes.py 2>&1 | grep -v amdgpu > $O/irse_shapes.txt || true
+echo winograd done
 timeout -k 10 200 python3 tools/cfg_selections.py $O/cfg_selections.txt > /dev/null 2>&1 || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/issue_probe.hip -o /tmp/issue_probe 2> /dev/null && /tmp/issue_probe > $O/issue_probe.txt 2>&1 || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/dma_probe.hip -o /tmp/dma_probe 2> /dev/null && /tmp/dma_probe > $O/dma_probe.txt 2>&1 || true
 echo extras done
