@@ -166,6 +166,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// FUSED: U in the A-operand order of wino4_fused_kernel, uf[36][K/8][2][N][4]: (xi, kc, h, n, c) = U[xi][n][8*kc + 2*c + h]
+template <bool FUSED>
 __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ wp, float* __restrict__ u, int K, int N) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)K * N) return;
@@ -196,7 +198,10 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
         double o[6];
         row(t[i][0], t[i][1], t[i][2], o);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) u[((int64_t)(i * 6 + j) * N + n) * K + k] = (float)o[j];
+        for (int j = 0; j < 6; ++j) {
+            if (FUSED) u[((((int64_t)(i * 6 + j) * (K >> 3) + kc) * 2 + h) * N + n) * 4 + c] = (float)o[j];
+            else u[((int64_t)(i * 6 + j) * N + n) * K + k] = (float)o[j];
+        }
     }
 }
 
@@ -318,6 +323,155 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------- F(4x4, 3x3), fused
+// The 32- and 64-channel layers at 512^2 / 1024^2: their transform-domain tensors (2.25x the input and the output, written and
+// read) cost more HBM time than the 4x fewer FLOPs return, so here V and M never leave the CU.  One workgroup = one block of
+// 32 output tiles (8 x 4 tiles = 32 x 16 pixels) x all N = 32*NB output channels; 4*NB waves; wave (nb, g) owns the 9 transform
+// positions xi = 9g .. 9g+8 of output-channel block nb: 9 accumulators of 32 channels x 32 tiles.  Per 8-channel chunk:
+//   threads 0..255: one (tile, channel) each -- the 6x6 window straight from global memory (prefetched during the previous chunk's
+//     MFMAs), B^T.B, in_scale, 36 scalars into the LDS image V[xi][half][tile] (float4 = the 4 channel pairs: one ds_read_b128 is
+//     the B operand of 4 MFMAs)
+//   every wave: for its 9 positions, A = one float4 of the transformed weights (global, L2-resident: 36*K*N floats) x B -> 4 MFMAs
+// then the products go through LDS in 4 rounds of 8 output channels ([xi][n8][tile], the same bytes as V) to the threads that
+// own an (output channel, tile) pair: A^T.A, out_scale and the epilogues of wino4_output_kernel, four 16-byte row stores.
+template <int NB, int ACT, bool DOT>
+__global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void wino4_fused_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                               const float* __restrict__ uf, const float* __restrict__ out_scale,
+                                                               float* __restrict__ y, int B, int K, int H, int W,
+                                                               const float* __restrict__ noise, const float* __restrict__ noise_w,
+                                                               const float* __restrict__ bias, const float* __restrict__ slope,
+                                                               const float* __restrict__ dot_with, float* __restrict__ dot_out) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int N = 32 * NB;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // V: 36*2*32 float4; later M: NB*36*8*32 floats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, j = lane & 31;
+    const int nb = wave >> 2, g = wave & 3;
+    const int bx_n = W >> 5, by_n = H >> 4;
+    const int blk = blockIdx.x;
+    const int bx = blk % bx_n, by = (blk / bx_n) % by_n, b = blk / (bx_n * by_n);
+    const int KC = K >> 3;
+    // transform role (threads 0..255): tile tj of the block, channel tch of the chunk
+    const int tj = tid & 31, tch = (tid >> 5) & 7;
+    const bool xform = tid < 256;
+    const int py0 = by * 16 + 4 * (tj >> 3), px0 = bx * 32 + 4 * (tj & 7);
+    float win[6][6];
+    auto load_win = [&](int kc) __attribute__((always_inline)) {
+        const float* xp = x + ((int64_t)b * K + kc * 8 + tch) * H * W;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = py0 - 1 + r;
+            const bool rin = iy >= 0 && iy < H;
+            const float* row = xp + (int64_t)(rin ? iy : 0) * W + px0;
+            const float4 mid = rin ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
+            win[r][0] = (rin && px0 > 0) ? row[-1] : 0.f;
+            win[r][1] = mid.x, win[r][2] = mid.y, win[r][3] = mid.z, win[r][4] = mid.w;
+            win[r][5] = (rin && px0 + 4 < W) ? row[4] : 0.f;
+        }
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    if (xform) load_win(0);
+    const float4* uf4 = reinterpret_cast<const float4*>(uf);
+    const float4* vs4 = reinterpret_cast<const float4*>(wsm);
+    for (int kc = 0; kc < KC; ++kc) {
+        if (xform) {
+            const float sc = in_scale ? in_scale[(int64_t)b * K + kc * 8 + tch] : 1.f;
+            float t[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) wino4_bt(win[r], t[r]);
+            float* vp = wsm + ((tch & 1) * 32 + tj) * 4 + (tch >> 1);  // [xi][half = tch & 1][tile][c = tch >> 1]
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                const float col[6] = {t[0][jj], t[1][jj], t[2][jj], t[3][jj], t[4][jj], t[5][jj]};
+                float o[6];
+                wino4_bt(col, o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) vp[(i * 6 + jj) * 256] = sc * o[i];
+            }
+        }
+        __syncthreads();
+        if (xform && kc + 1 < KC) load_win(kc + 1);  // in flight during this chunk's MFMAs
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int xi = 9 * g + q;
+            const float4 a4 = uf4[(((int64_t)xi * KC + kc) * 2 + half) * N + nb * 32 + j];
+            const float4 b4 = vs4[(xi * 2 + half) * 32 + j];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[q], 0, 0, 0);
+        }
+        __syncthreads();  // (the next chunk's transform overwrites V)
+    }
+    // ---- output: 4 rounds of 8 output channels per block of 32.  Accumulator register r of lane (half, j) is row
+    // (r & 3) + 8 * (r >> 2) + 4 * half, column j: round q4 moves the registers 4*q4 .. 4*q4+3 = rows 8*q4 .. 8*q4+7.
+    const int oj = tid & 31, on8 = (tid >> 5) & 7, onb = tid >> 8;
+    const int opy = by * 16 + 4 * (oj >> 3), opx = bx * 32 + 4 * (oj & 7);
+    const int64_t opix = (int64_t)opy * W + opx;
+    const float nw = (ACT == 1 && noise) ? noise_w[0] : 0.f;
+#pragma unroll 1
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) wsm[((nb * 36 + 9 * g + q) * 8 + rr + 4 * half) * 32 + j] = acc[q][4 * q4 + rr];
+        __syncthreads();
+        const int n = onb * 32 + 8 * q4 + on8;
+        const float* mp = wsm + (onb * 36 * 8 + on8) * 32 + oj;
+        float s[4][6];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            float col[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = mp[(i * 6 + jj) * 256];
+            float o[4];
+            wino4_at(col, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i][jj] = o[i];
+        }
+        const int64_t plane = (int64_t)b * N + n;
+        const float os = out_scale ? out_scale[plane] : 1.f;
+        const float bs = (ACT && bias) ? bias[n] : 0.f;
+        const float sl = (ACT == 2 && slope) ? slope[n] : 1.f;
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float o[4];
+            wino4_at(s[i], o);
+            if (DOT) {
+                const float4 d = *reinterpret_cast<const float4*>(dot_with + plane * H * W + opix + (int64_t)i * W);
+                part += (o[0] * d.x + o[1] * d.y) + (o[2] * d.z + o[3] * d.w);
+            }
+            float4 r = make_float4(o[0] * os, o[1] * os, o[2] * os, o[3] * os);
+            if (ACT == 1) {
+                float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (noise) nz = *reinterpret_cast<const float4*>(noise + opix + (int64_t)i * W);
+                r.x += nw * nz.x + bs, r.y += nw * nz.y + bs, r.z += nw * nz.z + bs, r.w += nw * nz.w + bs;
+                r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
+                r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
+            }
+            if (ACT == 2) {
+                r.x += bs, r.y += bs, r.z += bs, r.w += bs;
+                r.x = r.x > 0.f ? r.x : sl * r.x, r.y = r.y > 0.f ? r.y : sl * r.y;
+                r.z = r.z > 0.f ? r.z : sl * r.z, r.w = r.w > 0.f ? r.w : sl * r.w;
+            }
+            *reinterpret_cast<float4*>(y + plane * H * W + opix + (int64_t)i * W) = r;
+        }
+        if (DOT) {  // the 32 tiles of a half-wave share (b, n)
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (oj == 0) atomicAdd(dot_out + plane, part);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace w2e
 
 using namespace w2e;
@@ -330,7 +484,7 @@ int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, int m, void*
     W2E_REQUIRE(m == 2 || m == 4, "wino_weights: output tile %d (2 or 4)", m);
     const int64_t total = (int64_t)k_ch * n_ch;
     if (m == 2) wino_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, u, k_ch, n_ch);
-    else wino4_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, u, k_ch, n_ch);
+    else wino4_weights_kernel<false><<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, u, k_ch, n_ch);
     W2E_LAUNCH_CHECK("wino_weights");
     return 0;
 }
@@ -386,6 +540,60 @@ int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch
         else wino4_output_kernel<0, false><<<grid, 256, 0, s>>>(mm, out_scale, y, batch, n_ch, h, w, seg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     W2E_LAUNCH_CHECK("wino_output");
+    return 0;
+}
+
+int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void* stream) {
+    W2E_REQUIRE(wp && uf, "wino_weights_fused: null tensor");
+    W2E_REQUIRE(k_ch > 0 && (k_ch & 7) == 0 && (n_ch == 32 || n_ch == 64), "wino_weights_fused: K %% 8 == 0, N = 32 or 64 (got %d, %d)", k_ch, n_ch);
+    const int64_t total = (int64_t)k_ch * n_ch;
+    wino4_weights_kernel<true><<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, uf, k_ch, n_ch);
+    W2E_LAUNCH_CHECK("wino_weights_fused");
+    return 0;
+}
+
+int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const float* out_scale, float* y, int batch, int k_ch,
+                   int n_ch, int h, int w, int act, const float* noise, const float* noise_w, const float* bias, const float* slope,
+                   const float* dot_with, float* dot_out, void* stream) {
+    W2E_REQUIRE(x && uf && y, "wino_fused: null tensor");
+    W2E_REQUIRE(act >= 0 && act <= 2, "wino_fused: epilogue %d (0 none, 1 StyledConv, 2 bias + PReLU)", act);
+    W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && (n_ch == 32 || n_ch == 64), "wino_fused: K %% 8 == 0, N = 32 or 64 (got %d, %d)", k_ch, n_ch);
+    W2E_REQUIRE(h >= 16 && w >= 32 && (h & 15) == 0 && (w & 31) == 0, "wino_fused: H %% 16 == 0 and W %% 32 == 0 (got %d x %d)", h, w);
+    W2E_REQUIRE(!(act && dot_with), "wino_fused: the activation epilogues and the fused dot exclude each other");
+    W2E_REQUIRE(!dot_with || dot_out, "wino_fused: dot_with without dot_out");
+    W2E_REQUIRE(!noise || noise_w, "wino_fused: noise without noise_w");
+    W2E_REQUIRE(act == 1 || !noise, "wino_fused: noise belongs to epilogue 1");
+    W2E_REQUIRE(act == 2 || !slope, "wino_fused: slope belongs to epilogue 2");
+    W2E_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)uf | (uintptr_t)(dot_with ? dot_with : y) | (uintptr_t)(noise ? noise : y)) & 15) == 0,
+                "wino_fused: x / y / uf / dot_with / noise must be 16-byte aligned");
+    if (batch == 0) return 0;
+    const int64_t blocks = (int64_t)batch * (h >> 4) * (w >> 5);
+    W2E_REQUIRE(blocks < ((int64_t)1 << 31), "wino_fused: too many tile blocks");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)blocks;
+#define W2E_WF(NBv)                                                                                                                       \
+    do {                                                                                                                                   \
+        const size_t lds = (size_t)NBv * 36 * 8 * 32 * 4;                                                                                  \
+        static unsigned done[3];                                                                                                           \
+        if (act == 1) {                                                                                                                    \
+            W2E_REQUIRE(big_lds_once((const void*)wino4_fused_kernel<NBv, 1, false>, &done[0]), "wino_fused: cannot enable %zu B of LDS", lds); \
+            wino4_fused_kernel<NBv, 1, false><<<grid, 256 * NBv, lds, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, h, w, noise, noise_w, bias, nullptr, nullptr, nullptr); \
+        } else if (act == 2) {                                                                                                             \
+            W2E_REQUIRE(big_lds_once((const void*)wino4_fused_kernel<NBv, 2, false>, &done[1]), "wino_fused: cannot enable %zu B of LDS", lds); \
+            wino4_fused_kernel<NBv, 2, false><<<grid, 256 * NBv, lds, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, h, w, nullptr, nullptr, bias, slope, nullptr, nullptr); \
+        } else if (dot_with) {                                                                                                             \
+            W2E_REQUIRE(big_lds_once((const void*)wino4_fused_kernel<NBv, 0, true>, &done[2]), "wino_fused: cannot enable %zu B of LDS", lds); \
+            wino4_fused_kernel<NBv, 0, true><<<grid, 256 * NBv, lds, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, h, w, nullptr, nullptr, nullptr, nullptr, dot_with, dot_out); \
+        } else {                                                                                                                           \
+            static unsigned done0;                                                                                                         \
+            W2E_REQUIRE(big_lds_once((const void*)wino4_fused_kernel<NBv, 0, false>, &done0), "wino_fused: cannot enable %zu B of LDS", lds); \
+            wino4_fused_kernel<NBv, 0, false><<<grid, 256 * NBv, lds, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, h, w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); \
+        }                                                                                                                                  \
+    } while (0)
+    if (n_ch == 32) W2E_WF(1);
+    else W2E_WF(2);
+#undef W2E_WF
+    W2E_LAUNCH_CHECK("wino_fused");
     return 0;
 }
 

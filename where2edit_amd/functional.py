@@ -257,12 +257,19 @@ WINOGRAD = {"0": False, "2": 2, "4": 4, "f2": "f2"}.get(os.environ.get("W2E_WINO
 WINO_LOG = None  # a list: every Winograd-form conv appends one line in the format of the library's tune_print (tests, tools/cfg_selections.py)
 
 
+FUSED = 8  # form code of the fused F(4x4,3x3) kernel (w2e_wino_fused)
+
+
 def set_winograd(mode):
-    """mode: "auto" | "f2" | False | 2 | 4"""
+    """mode: "auto" | "f2" | False | 2 | 4 | 8 (8: the fused F(4x4,3x3) kernel wherever its shapes allow)"""
     global WINOGRAD
-    if mode not in ("auto", "f2", False, 2, 4):
-        raise ValueError("set_winograd: 'auto', 'f2', False, 2 or 4")
+    if mode not in ("auto", "f2", False, 2, 4, 8):
+        raise ValueError("set_winograd: 'auto', 'f2', False, 2, 4 or 8")
     WINOGRAD = mode
+
+
+def _fused_shape_ok(b, k, n, h, w):
+    return b > 0 and n in (32, 64) and k % 8 == 0 and h % 16 == 0 and w % 32 == 0 and b * (h // 16) * (w // 32) < 2 ** 31
 
 
 def _wino_shape_ok(m, b, k, n, h, w, dot=True):
@@ -279,11 +286,17 @@ def _wino_form(x, k, n, h, w, dot_with):
     b = x.shape[0]
     if WINOGRAD == "auto":
         m = 4 if (k >= 128 and n >= 128 and 16 <= h <= 256 and 16 <= w <= 256) else 0
+        if not m and k <= 64 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w) and (dot_with is None or k >= 64):
+            m = FUSED  # the 64- and 32-channel layers at 512^2 / 1024^2 (not the 32-channel input-gradient pass: its per-block
+            #            atomics of the fused dot cost more than the form returns, 0.93 vs 0.72 ms at batch 4)
     elif WINOGRAD == "f2":
         m = 2 if (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128) else 0
     else:
         m = WINOGRAD
-    if not m or not _wino_shape_ok(m, b, k, n, h, w, dot_with is not None):
+    if m == FUSED:
+        if not _fused_shape_ok(b, k, n, h, w):
+            return 0
+    elif not m or not _wino_shape_ok(m, b, k, n, h, w, dot_with is not None):
         return 0
     if _lib.get_option("conv_precision") != 0 or (dot_with is not None and _lib.get_option("deterministic")):
         return 0
@@ -301,8 +314,27 @@ def _wino_weights(wp, k, n, m):
     return u
 
 
+def _wino_weights_fused(wp, k, n):
+    uf = getattr(wp, "_w2e_wino_uf", None)
+    if uf is None:
+        uf = torch.empty((36, k // 8, 2, n, 4), device=wp.device, dtype=torch.float32)
+        call("w2e_wino_weights_fused", ptr(wp), ptr(uf), k, n, stream_ptr())
+        wp._w2e_wino_uf = uf
+    return uf
+
+
 def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot):
     b = x.shape[0]
+    if m == FUSED:
+        if WINO_LOG is not None:
+            WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) fused{', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
+                            f"{b * (h // 16) * (w // 32)} blocks of 32 tiles")
+        noise = noise_w = bias = None
+        if act is not None:
+            noise, noise_w, bias = act
+        call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
+             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), None, ptr(dot_with), ptr(dot), stream_ptr())
+        return
     tiles = b * (h // m) * (w // m)
     if WINO_LOG is not None:
         WINO_LOG.append(f"modconv mode 0 (winograd F({m}x{m},3x3){', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
@@ -340,7 +372,7 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
         noise, noise_w, bias = act
     # algorithmic FLOPs: 2*K*N*9 per domain pixel (MACs actually needed; SURVEY 2.3 convention)
     form = _wino_form(x, k, n, h, w, dot_with) if mode == MODE_SAME else 0
-    sp = profiling.span("modconv3x3_wino%d" % form if form else "modconv3x3", 2.0 * b * k * n * 9 * h * w)
+    sp = profiling.span("modconv3x3_wino%d" % (4 if form == FUSED else form) if form else "modconv3x3", 2.0 * b * k * n * 9 * h * w)
     if form:
         _modconv_wino(form, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot)
     else:
