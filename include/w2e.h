@@ -153,14 +153,18 @@ int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch
                     const float* noise, const float* noise_w, const float* bias, const float* slope, const float* dot_with,
                     float* dot_out, void* stream);
 
-/* The FUSED F(4x4,3x3) form for the narrow, high-resolution layers (N = 32 or 64 output channels, K % 8 == 0, H % 16 == 0,
+/* The FUSED F(4x4,3x3) form for the narrow, high-resolution layers (N % 32 == 0 output channels, K % 8 == 0, H % 16 == 0,
  * W % 32 == 0): input transform, the 36 contractions (fp32 MFMA) and the output transform in ONE kernel -- V and M, 2.25x the
  * input / output each, never leave the CU (through HBM they cost more than the 4x fewer FLOPs return at these sizes).  Same
- * arguments, epilogues and rounding as w2e_wino_output (m = 4) after w2e_wino_input; uf [36][K/8][2][N][4] from w2e_wino_weights_fused. */
+ * arguments, epilogues and rounding as w2e_wino_output (m = 4) after w2e_wino_input; uf [36][K/8][2][N][4] from w2e_wino_weights_fused.
+ *   version 2 (the one the host uses): persistent workgroups of 4 matrix + 4 loader waves; K a power of two >= 32; the fused dot is
+ *     NOT accumulated: dot_out receives one partial per (channel, spatial block), [batch][N][H/16 * W/32] floats (written, no
+ *     atomics: deterministic), which the caller sums over the last axis (w2e_channel_sums).  wgs > 0 caps the persistent grid (tests).
+ *   version 1: one workgroup per block, N = 32 or 64, any K % 8 == 0; dot_out [B,N] accumulated with atomics. */
 int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void* stream);
 int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const float* out_scale, float* y, int batch, int k_ch,
                    int n_ch, int h, int w, int act, const float* noise, const float* noise_w, const float* bias, const float* slope,
-                   const float* dot_with, float* dot_out, void* stream);
+                   const float* dot_with, float* dot_out, int version, int wgs, void* stream);
 
 /* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
  *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */

@@ -1002,13 +1002,16 @@ def test_modconv_pipelined_kernel(b, k, n, h, w, wgs, w2e_opt):
 @pytest.mark.parametrize("m,b,k,n,h,w", [(2, 2, 64, 48, 16, 16), (2, 1, 24, 40, 32, 16), (2, 3, 512, 512, 16, 16), (2, 2, 16, 16, 64, 32),
                                          (4, 3, 64, 48, 16, 16), (4, 1, 24, 40, 32, 32), (4, 2, 512, 512, 32, 32), (4, 5, 16, 16, 64, 32),
                                          (4, 2, 128, 128, 16, 32),
-                                         (8, 2, 32, 32, 32, 64), (8, 1, 64, 64, 16, 32), (8, 3, 40, 32, 48, 32), (8, 2, 64, 32, 32, 32), (8, 1, 16, 64, 64, 64)])
+                                         (8, 2, 32, 32, 32, 64), (8, 1, 64, 64, 16, 32), (8, 3, 128, 32, 48, 32), (8, 2, 64, 32, 32, 32), (8, 5, 32, 64, 64, 64),
+                                         (8, 2, 32, 128, 32, 32), (9, 3, 40, 32, 48, 32), (9, 2, 32, 64, 32, 64)])
 def test_modconv_winograd_form(m, b, k, n, h, w):
     """K1w: the Winograd forms F(2x2,3x3) and F(4x4,3x3) of the same-resolution conv (w2e_wino_weights / _input / _output around one
     strided-batched fp32 GEMM) against float64 convolutions, every epilogue of w2e_modconv3x3 -- plain, unmodulated, noise + bias +
     LeakyReLU, and the input-gradient pass (transposed + flipped pack) with the fused per-channel dot (16 tiles per plane: the
     segmented reduction; 64 and more: whole waves) -- and against the direct kernel; m = 8: the FUSED F(4x4,3x3) kernel
-    (w2e_wino_fused: N = 32 / 64, one and several 32-tile blocks per image, K not a multiple of 32, image borders on every side).  Tolerances: FWD_TOL = 1e-4 against float64
+    (w2e_wino_fused version 2 -- persistent, loader + matrix waves, a grid of 3 workgroups so that each walks through several
+    blocks, 1 to 4 output-channel blocks, K = 32 ... 128, the fused dot as per-block partials -- and, m = 9, version 1: one workgroup
+    per block, K not a power of two, atomics), image borders on every side.  Tolerances: FWD_TOL = 1e-4 against float64
     for both; the measured distance is printed by -s (F(2x2): ~6e-7, F(4x4): ~1e-5 at K = 512)."""
     import torch.nn.functional as F
     from where2edit_amd import functional as K
@@ -1028,7 +1031,10 @@ def test_modconv_winograd_form(m, b, k, n, h, w):
     gy = torch.randn(b, n, h, w, generator=g).to(DEV)          # the input-gradient pass: in_scale = s_out (demod), out_scale = s_in
     xdot = torch.randn(b, k, h, w, generator=g).to(DEV)
     graw = F.conv_transpose2d(gy.double() * so, wd, padding=1)
-    saved = K.WINOGRAD
+    saved, saved_f = K.WINOGRAD, (K.FUSED_VERSION, K.FUSED_WGS)
+    if m >= 8:
+        K.FUSED_VERSION, K.FUSED_WGS = (2, 3) if m == 8 else (1, 0)
+        m = 8
     try:
         K.set_winograd(False)
         y_direct, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
@@ -1054,3 +1060,4 @@ def test_modconv_winograd_form(m, b, k, n, h, w):
         assert float(out[0].min()) == 7.0 and float(out[0].max()) == 7.0
     finally:
         K.set_winograd(saved)
+        K.FUSED_VERSION, K.FUSED_WGS = saved_f

@@ -307,9 +307,9 @@ def test_bench_workload2_step_matches_oracle(batch, capfd):
         wino, KF.WINO_LOG = KF.WINO_LOG, None
     n_conv = sum(ln.startswith("modconv mode") for ln in capfd.readouterr().err.splitlines())
     # 17 forward launches over the merged batch [w; w_hat] + 17 input-gradient launches over the w_hat rows; of each 17, the
-    # same-resolution layers with >= 128 channels at 16^2 ... 256^2 (5 + 5) take the Winograd form, 64 @ 512^2 (forward and backward)
-    # and 32 @ 1024^2 (forward) its fused kernel, the rest the direct kernels
-    assert n_conv + len(wino) == 34 and len(wino) == (13 if KF.WINOGRAD == "auto" else 0), (n_conv, wino)
+    # same-resolution layers with >= 128 channels at 16^2 ... 256^2 (5 + 5) take the Winograd form, 64 @ 512^2 and 32 @ 1024^2
+    # (2 + 2) its fused kernels, the rest the direct kernels
+    assert n_conv + len(wino) == 34 and len(wino) == (14 if KF.WINOGRAD == "auto" else 0), (n_conv, wino)
     st = size // 64
     assert_close(x[:, :, ::st, ::st], x_o[:, :, ::st, ::st], 1e-4, "x = G(w) (strided sample)")
     assert_close(x_hat, xh_o, 1e-4, "x_hat (all pixels)"), assert_close(w_hat, wh_o, 1e-5, "w_hat")

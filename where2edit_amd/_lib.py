@@ -41,7 +41,7 @@ _PROTOS = {
     "w2e_wino_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "w2e_wino_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "w2e_wino_weights_fused": (_I, [_P, _P, _I, _I, _P]),
-    "w2e_wino_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "w2e_wino_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "w2e_wino_output": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "w2e_demod_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "w2e_demod_all_fwd": (_I, [ctypes.POINTER(DemodLayer), _I, _I, _F, _P]),

@@ -472,6 +472,270 @@ __global__ __launch_bounds__(256 * NB, NB == 1 ? 2 : 1) void wino4_fused_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------- F(4x4, 3x3), fused, persistent + specialised waves
+// wino4_fused_kernel above keeps V and M on the CU but its threads wait on their own window loads: the MFMAs of a chunk (36 per
+// wave, ~2.3 k cycles) are far too short to cover an HBM round trip, and its registers (250) leave no room to keep more in flight.
+// Here a workgroup is 8 waves with two jobs:
+//   waves 4..7 ("loaders")  one (tile, channel) each per 8-channel chunk: window loads FOUR chunks ahead (4 x 36 registers: these waves
+//                            have no accumulators), B^T.B, 36 scalars into the V stage of the chunk
+//   waves 0..3 ("matrix")   9 transform positions each: A = transformed weights (global, L2; prefetched one chunk ahead) x B from the
+//                            V stage -> 36 MFMAs per chunk; then the block's output rounds through their own LDS buffer
+// and it is persistent over (spatial block, 32-channel output block) pairs, so the loaders run into the next block while the matrix
+// waves are in their output rounds.  Everybody advances in lock-step "ticks" (one barrier each): a matrix tick consumes chunk t from
+// V[t & 1] while the loaders write chunk t+1 into V[(t+1) & 1]; an output tick is half an output round.  The loaders may be at most
+// two chunks ahead (both stages full).  Output channels: any multiple of 32 (blockIdx.y).  K: a power of two >= 32.
+typedef float wf_f32x16 __attribute__((ext_vector_type(16)));
+
+// The 6x6 window of one (tile, channel): per row one 16-byte and two 4-byte buffer loads, UNCONDITIONAL -- rows / columns outside the
+// image and whole chunks past the last block get an offset past the descriptor and read 0 -- so that the loader's stream has no
+// branches around its loads and the compiler's vmcnt bookkeeping stays exact (with `cond ? *p : 0` loads every wait became vmcnt(0)).
+// `base`: byte offset of the window's plane in x, or the marker for "nothing to load".
+__device__ __forceinline__ void wf2_load(float (&win)[36], const __amdgpu_buffer_rsrc_t rx, unsigned base, int py0, int px0, int H, int W) {
+    typedef float wf_f32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned kOut = 0xfffffff0u;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int iy = py0 - 1 + r;
+        const bool rin = base != kOut && iy >= 0 && iy < H;
+        const unsigned off = base + (unsigned)(iy * W + px0) * 4u;
+        const wf_f32x4 mid = __builtin_bit_cast(wf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, rin ? off : kOut, 0, 0));
+        win[r * 6 + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (rin && px0 > 0) ? off - 4u : kOut, 0, 0));
+        win[r * 6 + 1] = mid[0], win[r * 6 + 2] = mid[1], win[r * 6 + 3] = mid[2], win[r * 6 + 4] = mid[3];
+        win[r * 6 + 5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (rin && px0 + 4 < W) ? off + 16u : kOut, 0, 0));
+    }
+}
+
+__device__ __forceinline__ void wf2_transform(const float (&win)[36], float* __restrict__ vp, float sc) {
+    float t[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float d[6] = {win[r * 6 + 0], win[r * 6 + 1], win[r * 6 + 2], win[r * 6 + 3], win[r * 6 + 4], win[r * 6 + 5]};
+        wino4_bt(d, t[r]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+        const float col[6] = {t[0][jj], t[1][jj], t[2][jj], t[3][jj], t[4][jj], t[5][jj]};
+        float o[6];
+        wino4_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vp[(i * 6 + jj) * 256] = sc * o[i];
+    }
+}
+
+template <int ACT, bool DOT>
+__global__ __launch_bounds__(512, 1) void wino4_fused2_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                              const float* __restrict__ uf, const float* __restrict__ out_scale,
+                                                              float* __restrict__ y, int B, int K, int N, int H, int W, int kc_log2,
+                                                              int n_blocks, const float* __restrict__ noise,
+                                                              const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                              const float* __restrict__ slope, const float* __restrict__ dot_with,
+                                                              float* __restrict__ dot_partial, int skip) {
+#ifndef W2E_TUNING
+    skip = 0;  // (work-skipping exists in tuning builds only: bit 0 no window loads after the first, 1 no transform, 2 no MFMAs, 3 no output rounds)
+#endif
+    constexpr int VS = 36 * 2 * 32 * 4;  // floats of one V stage; the output buffer M[36][16][32] is two of them
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // V[2][VS], M[2 * VS]
+    float* const mbuf = wsm + 2 * VS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx_n = W >> 5, by_n = H >> 4, per_img = bx_n * by_n;
+    const int KC = 1 << kc_log2;
+    const int count = (n_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n0 = blockIdx.y * 32;
+    // ---- the output of a block, shared by both roles: 2 rounds of 16 output channels; in each the matrix waves park their products in
+    // M[xi][n16][tile] (tick A), then ALL 512 threads own one (channel, tile) pair: A^T.A, epilogue, four 16-byte row stores (tick B).
+    // The per-pair operands of the epilogue (noise row quads, scales) are fetched in tick A so that they have landed in tick B.
+    const int oj = tid & 31, on16 = tid >> 5;
+    const float nw = (ACT == 1 && noise) ? noise_w[0] : 0.f;
+    struct OutPre {
+        float4 nz[4];
+        float os, bs, sl;
+    };
+    auto out_prefetch = [&](OutPre& pre, int b, int64_t opix, int n) __attribute__((always_inline)) {
+        const int64_t plane = (int64_t)b * N + n;
+        pre.os = out_scale ? out_scale[plane] : 1.f;
+        pre.bs = (ACT && bias) ? bias[n] : 0.f;
+        pre.sl = (ACT == 2 && slope) ? slope[n] : 1.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            pre.nz[ii] = (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + opix + (int64_t)ii * W) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto out_items = [&](const OutPre& pre, int blk, int b, int64_t opix, int n) __attribute__((always_inline)) {
+        if (skip & 8) return;
+        const float* mp = mbuf + on16 * 32 + oj;
+        float s[4][6];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            float col[6];
+#pragma unroll
+            for (int ii = 0; ii < 6; ++ii) col[ii] = mp[(ii * 6 + jj) * 512];
+            float o[4];
+            wino4_at(col, o);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) s[ii][jj] = o[ii];
+        }
+        const int64_t plane = (int64_t)b * N + n;
+        float part = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            float o[4];
+            wino4_at(s[ii], o);
+            if (DOT) {
+                const float4 d = *reinterpret_cast<const float4*>(dot_with + plane * H * W + opix + (int64_t)ii * W);
+                part += (o[0] * d.x + o[1] * d.y) + (o[2] * d.z + o[3] * d.w);
+            }
+            float4 r = make_float4(o[0] * pre.os, o[1] * pre.os, o[2] * pre.os, o[3] * pre.os);
+            if (ACT == 1) {
+                const float4 nz = pre.nz[ii];
+                r.x += nw * nz.x + pre.bs, r.y += nw * nz.y + pre.bs, r.z += nw * nz.z + pre.bs, r.w += nw * nz.w + pre.bs;
+                r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
+                r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
+            }
+            if (ACT == 2) {
+                r.x += pre.bs, r.y += pre.bs, r.z += pre.bs, r.w += pre.bs;
+                r.x = r.x > 0.f ? r.x : pre.sl * r.x, r.y = r.y > 0.f ? r.y : pre.sl * r.y;
+                r.z = r.z > 0.f ? r.z : pre.sl * r.z, r.w = r.w > 0.f ? r.w : pre.sl * r.w;
+            }
+            *reinterpret_cast<float4*>(y + plane * H * W + opix + (int64_t)ii * W) = r;
+        }
+        if (DOT) {  // the 32 tiles of a half-wave share (b, n): one partial per (channel, spatial block of the image), summed by the caller
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (oj == 0) dot_partial[((int64_t)b * N + n) * per_img + (blk - b * per_img)] = part;
+        }
+    };
+    auto block_pix = [&](int blk, int& b, int64_t& opix) __attribute__((always_inline)) {
+        b = blk / per_img;
+        const int rem = blk - b * per_img;
+        const int by = rem / bx_n, bx = rem - by * bx_n;
+        opix = (int64_t)(by * 16 + 4 * (oj >> 3)) * W + bx * 32 + 4 * (oj & 7);
+    };
+    // The two roles are two separate loops with the SAME sequence of barriers (per block: KC matrix ticks, then 4 output ticks), so
+    // that each gets its own register allocation: accumulators there, window sets here.
+    if (wave >= 4) {
+        // ---------------------------------------------------------------------------------------------- loaders
+        // Static schedule (so that the window sets are compile-time registers and the compiler's vmcnt waits stay exact): chunk kc of a
+        // block lives in set kc % 4 and is produced at a fixed tick -- chunk c+1 at matrix tick c (c >= 1), the NEXT block's chunk 0
+        // at the last matrix tick and its chunk 1 at the first output tick; matrix tick 0 is idle.  The loads of the chunk four
+        // positions later are issued right behind each transform.  KC % 4 == 0.
+        const int tj = tid & 31, tch = (tid >> 5) & 7;  // tile of a block, channel of a chunk
+        float w0[36], w1[36], w2[36], w3[36];
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), (short)0, (int)(unsigned)((int64_t)B * K * H * W * 4), 0x00020000);
+        auto issue = [&](float (&win)[36], int bi, int kc) __attribute__((always_inline)) {  // chunk kc of this workgroup's block number bi
+            const bool live = bi < count && !((skip & 1) && (bi > 0 || kc >= 4));
+            const int blk = (int)blockIdx.x + (live ? bi : 0) * (int)gridDim.x;
+            const int b = blk / per_img, rem = blk - b * per_img;
+            const int by = rem / bx_n, bx = rem - by * bx_n;
+            const unsigned base = live ? (unsigned)(((int64_t)b * K + kc * 8 + tch) * H * W * 4) : 0xfffffff0u;
+            wf2_load(win, rx, base, by * 16 + 4 * (tj >> 3), bx * 32 + 4 * (tj & 7), H, W);
+        };
+        auto produce = [&](float (&win)[36], int bi, int kc) __attribute__((always_inline)) {  // -> V[kc & 1] (KC is even); then the loads 4 chunks on
+            if (bi < count) {
+                const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+                const int b = blk / per_img;
+                const float sc = in_scale ? in_scale[(int64_t)b * K + kc * 8 + tch] : 1.f;
+                if (!(skip & 2)) wf2_transform(win, wsm + (kc & 1) * VS + ((tch & 1) * 32 + tj) * 4 + (tch >> 1), sc);
+            }
+            const int nk = kc + 4;
+            issue(win, nk >= KC ? bi + 1 : bi, nk & (KC - 1));
+        };
+        issue(w0, 0, 0), issue(w1, 0, 1), issue(w2, 0, 2), issue(w3, 0, 3);
+        produce(w0, 0, 0), produce(w1, 0, 1);
+        __syncthreads();
+        for (int i = 0; i < count; ++i) {
+            __syncthreads();  // matrix tick 0: idle
+            for (int c = 1; c < KC - 1; c += 4) {  // matrix ticks c, c+1 (and c+2, c+3 unless they are past the last but one): chunks c+1 ...
+                produce(w2, i, c + 1);
+                __syncthreads();
+                produce(w3, i, c + 2);
+                __syncthreads();
+                if (c + 3 < KC) {
+                    produce(w0, i, c + 3);
+                    __syncthreads();
+                    produce(w1, i, c + 4);
+                    __syncthreads();
+                }
+            }
+            produce(w0, i + 1, 0);  // the last matrix tick (KC - 1)
+            __syncthreads();
+            const int blk = (int)blockIdx.x + i * (int)gridDim.x;
+            int b;
+            int64_t opix;
+            block_pix(blk, b, opix);
+            OutPre pre;
+            // output tick A0 (the next block's chunk 1 first), B0, A1, B1
+            produce(w1, i + 1, 1);
+            out_prefetch(pre, b, opix, n0 + on16);
+            __syncthreads();
+            out_items(pre, blk, b, opix, n0 + on16);
+            out_prefetch(pre, b, opix, n0 + 16 + on16);
+            __syncthreads();
+            __syncthreads();
+            out_items(pre, blk, b, opix, n0 + 16 + on16);
+            __syncthreads();
+        }
+        return;
+    }
+    // -------------------------------------------------------------------------------------------------- matrix waves
+    const int half = lane >> 5, j = lane & 31;
+    const int g = wave;
+    wf_f32x16 acc[9];
+    const float4* uf4 = reinterpret_cast<const float4*>(uf);
+    // A operands: one float4 per position, loaded ONE TICK AHEAD and in place -- a[q] is reloaded with the next chunk's weights right
+    // behind the four MFMAs that consumed it (the last tick of a block fetches chunk 0 again: the same weights serve the next block)
+    float4 a[9];
+    auto a_at = [&](int q, int kc) __attribute__((always_inline)) {
+        return uf4[((((int64_t)(9 * g + q) << kc_log2) + kc) * 2 + half) * N + n0 + j];
+    };
+    auto mfma_tick = [&](int stage, int next_kc) __attribute__((always_inline)) {
+        const float4* vs4 = reinterpret_cast<const float4*>(wsm + stage * VS);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const float4 b4 = vs4[((9 * g + q) * 2 + half) * 32 + j];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b4.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b4.y, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b4.z, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b4.w, acc[q], 0, 0, 0);
+            a[q] = a_at(q, next_kc);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = a_at(q, 0);
+    __syncthreads();  // (prologue tick)
+    for (int i = 0; i < count; ++i) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        for (int c = 0; c < KC; ++c) {
+            if (!(skip & 4)) mfma_tick(c & 1, (c + 1) & (KC - 1));
+            __syncthreads();
+        }
+        const int blk = (int)blockIdx.x + i * (int)gridDim.x;
+        int b;
+        int64_t opix;
+        block_pix(blk, b, opix);
+        OutPre pre;
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {  // (unrolled: the accumulator registers are indexed by q2)
+            // accumulator register r of lane (half, j) is row (r & 3) + 8 * (r >> 2) + 4 * half: round q2 moves the registers
+            // 8*q2 .. 8*q2+7 = rows 16*q2 .. 16*q2+15, row within the round n16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half
+            out_prefetch(pre, b, opix, n0 + 16 * q2 + on16);
+            if (!(skip & 8)) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+                        mbuf[((9 * g + q) * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * half) * 32 + j] = acc[q][8 * q2 + rr];
+            }
+            __syncthreads();
+            out_items(pre, blk, b, opix, n0 + 16 * q2 + on16);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace w2e
 
 using namespace w2e;
@@ -545,7 +809,7 @@ int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch
 
 int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void* stream) {
     W2E_REQUIRE(wp && uf, "wino_weights_fused: null tensor");
-    W2E_REQUIRE(k_ch > 0 && (k_ch & 7) == 0 && (n_ch == 32 || n_ch == 64), "wino_weights_fused: K %% 8 == 0, N = 32 or 64 (got %d, %d)", k_ch, n_ch);
+    W2E_REQUIRE(k_ch > 0 && (k_ch & 7) == 0 && n_ch > 0 && (n_ch & 31) == 0, "wino_weights_fused: K %% 8 == 0, N %% 32 == 0 (got %d, %d)", k_ch, n_ch);
     const int64_t total = (int64_t)k_ch * n_ch;
     wino4_weights_kernel<true><<<(unsigned)ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(wp, uf, k_ch, n_ch);
     W2E_LAUNCH_CHECK("wino_weights_fused");
@@ -554,10 +818,11 @@ int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void*
 
 int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const float* out_scale, float* y, int batch, int k_ch,
                    int n_ch, int h, int w, int act, const float* noise, const float* noise_w, const float* bias, const float* slope,
-                   const float* dot_with, float* dot_out, void* stream) {
+                   const float* dot_with, float* dot_out, int version, int wgs, void* stream) {
     W2E_REQUIRE(x && uf && y, "wino_fused: null tensor");
     W2E_REQUIRE(act >= 0 && act <= 2, "wino_fused: epilogue %d (0 none, 1 StyledConv, 2 bias + PReLU)", act);
-    W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && (n_ch == 32 || n_ch == 64), "wino_fused: K %% 8 == 0, N = 32 or 64 (got %d, %d)", k_ch, n_ch);
+    W2E_REQUIRE(version == 1 || version == 2, "wino_fused: version %d (1 or 2)", version);
+    W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && n_ch > 0 && (n_ch & 31) == 0, "wino_fused: K %% 8 == 0, N %% 32 == 0 (got %d, %d)", k_ch, n_ch);
     W2E_REQUIRE(h >= 16 && w >= 32 && (h & 15) == 0 && (w & 31) == 0, "wino_fused: H %% 16 == 0 and W %% 32 == 0 (got %d x %d)", h, w);
     W2E_REQUIRE(!(act && dot_with), "wino_fused: the activation epilogues and the fused dot exclude each other");
     W2E_REQUIRE(!dot_with || dot_out, "wino_fused: dot_with without dot_out");
@@ -571,6 +836,40 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
     W2E_REQUIRE(blocks < ((int64_t)1 << 31), "wino_fused: too many tile blocks");
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = (unsigned)blocks;
+    if (version == 2) {  // persistent, specialised waves: K a power of two >= 16; the fused dot leaves [blocks][N] partials
+        W2E_REQUIRE(k_ch >= 32 && (k_ch & (k_ch - 1)) == 0, "wino_fused v2: K must be a power of two >= 32 (got %d)", k_ch);
+        W2E_REQUIRE((int64_t)batch * k_ch * h * w * 4 < ((int64_t)1 << 32) - 64, "wino_fused v2: x exceeds 4 GB");
+        int kc_log2 = 0;
+        while ((8 << kc_log2) < k_ch) ++kc_log2;
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const int nby = n_ch / 32;
+        int gx = cus / nby;
+        if (gx < 1) gx = 1;
+        if (gx > blocks) gx = (int)blocks;
+        if ((wgs & 0xffff) > 0 && (wgs & 0xffff) < gx) gx = wgs & 0xffff;  // (tests: several blocks per workgroup on small inputs; bits 16+: a tuning build's skip mask)
+        const dim3 g2((unsigned)gx, (unsigned)nby);
+        const size_t lds2 = (size_t)4 * 36 * 2 * 32 * 4 * 4;
+        static unsigned done2[4];
+#define W2E_WF2(ACTv, DOTv, slot)                                                                                                          \
+    do {                                                                                                                                   \
+        W2E_REQUIRE(big_lds_once((const void*)wino4_fused2_kernel<ACTv, DOTv>, &done2[slot]), "wino_fused: cannot enable %zu B of LDS", lds2); \
+        wino4_fused2_kernel<ACTv, DOTv><<<g2, 512, lds2, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
+                                                             noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);                   \
+    } while (0)
+        if (act == 1) W2E_WF2(1, false, 0);
+        else if (act == 2) W2E_WF2(2, false, 1);
+        else if (dot_with) W2E_WF2(0, true, 2);
+        else W2E_WF2(0, false, 3);
+#undef W2E_WF2
+        W2E_LAUNCH_CHECK("wino_fused (v2)");
+        return 0;
+    }
+    W2E_REQUIRE(n_ch == 32 || n_ch == 64, "wino_fused v1: N = 32 or 64 (got %d)", n_ch);
 #define W2E_WF(NBv)                                                                                                                       \
     do {                                                                                                                                   \
         const size_t lds = (size_t)NBv * 36 * 8 * 32 * 4;                                                                                  \

@@ -268,8 +268,27 @@ def set_winograd(mode):
     WINOGRAD = mode
 
 
-def _fused_shape_ok(b, k, n, h, w):
-    return b > 0 and n in (32, 64) and k % 8 == 0 and h % 16 == 0 and w % 32 == 0 and b * (h // 16) * (w // 32) < 2 ** 31
+FUSED_VERSION = "auto"  # 1: one workgroup per 32-tile block (N = 32 / 64; atomics for the fused dot); 2: persistent, loader + matrix waves
+#                          (K a power of two >= 32, the fused dot as per-block partials); "auto": 1 for the forward epilogues (faster there:
+#                          64 -> 64 @ 512^2 batch 8 0.82 vs 0.90 ms), 2 for the input-gradient pass (0.47 vs 0.57 ms at batch 4: no atomics)
+FUSED_WGS = 0           # > 0: cap of version 2's persistent grid (tests)
+
+
+def _fused_version(k, n, dot):
+    v1_ok, v2_ok = n in (32, 64), (k >= 32 and k & (k - 1) == 0)
+    if FUSED_VERSION == 1:
+        return 1 if v1_ok else 0
+    if FUSED_VERSION == 2:
+        return 2 if v2_ok else 0
+    if dot:
+        return 2 if v2_ok else (1 if v1_ok else 0)
+    return 1 if v1_ok else (2 if v2_ok else 0)
+
+
+def _fused_shape_ok(b, k, n, h, w, dot=False):
+    if not (b > 0 and k % 8 == 0 and n % 32 == 0 and h % 16 == 0 and w % 32 == 0 and b * (h // 16) * (w // 32) < 2 ** 31):
+        return False
+    return _fused_version(k, n, dot) != 0
 
 
 def _wino_shape_ok(m, b, k, n, h, w, dot=True):
@@ -286,20 +305,21 @@ def _wino_form(x, k, n, h, w, dot_with):
     b = x.shape[0]
     if WINOGRAD == "auto":
         m = 4 if (k >= 128 and n >= 128 and 16 <= h <= 256 and 16 <= w <= 256) else 0
-        if not m and k <= 64 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w) and (dot_with is None or k >= 64):
-            m = FUSED  # the 64- and 32-channel layers at 512^2 / 1024^2 (not the 32-channel input-gradient pass: its per-block
-            #            atomics of the fused dot cost more than the form returns, 0.93 vs 0.72 ms at batch 4)
+        if not m and k <= 64 and n <= 64 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w, dot_with is not None):
+            m = FUSED  # the 64- and 32-channel layers at 512^2 / 1024^2
     elif WINOGRAD == "f2":
         m = 2 if (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128) else 0
     else:
         m = WINOGRAD
     if m == FUSED:
-        if not _fused_shape_ok(b, k, n, h, w):
+        if not _fused_shape_ok(b, k, n, h, w, dot_with is not None):
             return 0
     elif not m or not _wino_shape_ok(m, b, k, n, h, w, dot_with is not None):
         return 0
-    if _lib.get_option("conv_precision") != 0 or (dot_with is not None and _lib.get_option("deterministic")):
+    if _lib.get_option("conv_precision") != 0:
         return 0
+    if dot_with is not None and not (m == FUSED and _fused_version(k, n, True) == 2) and _lib.get_option("deterministic"):
+        return 0  # (their fused dot uses atomics; the fused kernel's partials are summed in a fixed order)
     return m if _lib.get_option("tune_cfg") < 0 else 0  # (a forced direct tile: tests, tools/layer_bench.py)
 
 
@@ -327,13 +347,23 @@ def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, d
     b = x.shape[0]
     if m == FUSED:
         if WINO_LOG is not None:
-            WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) fused{', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
-                            f"{b * (h // 16) * (w // 32)} blocks of 32 tiles")
+            WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) fused v{_fused_version(k, n, dot_with is not None)}{', dot' if dot_with is not None else ''}) "
+                            f"K {k} N {n} {h}x{w} B {b} -> {b * (h // 16) * (w // 32)} blocks of 32 tiles")
         noise = noise_w = bias = None
         if act is not None:
             noise, noise_w, bias = act
+        ver = _fused_version(k, n, dot_with is not None)
+        if dot_with is not None and ver == 2:  # one partial per (spatial block, channel): summed here, in a fixed order
+            nblk = (h // 16) * (w // 32)
+            part = torch.empty((b, n, nblk), device=x.device, dtype=torch.float32)
+            call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
+                 0, None, None, None, None, ptr(dot_with), ptr(part), 2, FUSED_WGS, stream_ptr())
+            sums = torch.empty((b, n), device=x.device, dtype=torch.float32)  # (a kernel, not aten::sum: that one memsets under capture)
+            call("w2e_channel_sums", ptr(part), None, ptr(sums), b, n, nblk, stream_ptr())
+            dot.add_(sums)
+            return
         call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
-             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), None, ptr(dot_with), ptr(dot), stream_ptr())
+             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), None, ptr(dot_with), ptr(dot), ver, FUSED_WGS, stream_ptr())
         return
     tiles = b * (h // m) * (w // m)
     if WINO_LOG is not None:
