@@ -44,7 +44,7 @@ def main():
     # every 3x3 modulated conv call of the step = a direct launch, or a Winograd-form call (one wino*_output launch each, with its
     # input transform and its GEMM): the `traffic` of bench.py's roofline is their HBM bytes per call
     conv = [k for k in f if k in w and ("modconv_kernel" in k or "wino" in k or k.startswith("Cijk_"))]
-    calls = sum(f[k][0] for k in conv if "modconv_kernel" in k or "_output_kernel" in k)
+    calls = sum(f[k][0] for k in conv if "modconv_kernel" in k or "_output_kernel" in k or "wino4_fused" in k)
     if calls:
         ft, wt = sum(f[k][1] for k in conv) / calls, sum(w[k][1] for k in conv) / calls
         lines.append(f"all 3x3 modulated conv calls (direct launches + Winograd-form calls), {calls}, {ft:.0f}, {wt:.0f}, {(2 * ft + wt) / 1024:.1f}, {(ft + wt) / 1024:.1f}")

@@ -22,7 +22,7 @@ for r in rows:
 # library's strided-batched GEMM + output transform; the Cijk_* rows also hold a few small stock-op GEMMs, < 0.06 ms per step)
 conv_t = sum(int(r["TotalDurationNs"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"]
              or "wino" in r["Name"] or r["Name"].startswith("Cijk_"))
-conv_c = sum(int(r["Calls"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"] or "_output_kernel" in r["Name"])
+conv_c = sum(int(r["Calls"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"] or "_output_kernel" in r["Name"] or "wino4_fused" in r["Name"])
 wino_t = sum(int(r["TotalDurationNs"]) for r in rows if "wino" in r["Name"] or r["Name"].startswith("Cijk_"))
 if conv_c:
     print(f"# all 3x3 modulated conv calls: {conv_t / steps / 1e6:.3f} ms/step, {conv_c / steps:.1f} calls/step, {conv_t / conv_c / 1e3:.1f} us per call "

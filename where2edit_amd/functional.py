@@ -253,7 +253,7 @@ MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 #           (1.16 ms against 0.64 for the GEMMs alone plus 3.5 GB of transform traffic).  Rounding ~1e-5 relative (direct: 3e-7)
 #   "f2"    F(2x2,3x3) wherever it beats the direct kernel (K, N >= 256 at 16^2 ... 128^2): rounding 6e-7, about half of "auto"'s gain
 #   False   direct kernels only ("0");  2 / 4: that form wherever the shapes allow (tests)
-WINOGRAD = {"0": False, "2": 2, "4": 4, "f2": "f2"}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
+WINOGRAD = {"0": False, "2": 2, "4": 4, "8": 8, "f2": "f2"}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
 WINO_LOG = None  # a list: every Winograd-form conv appends one line in the format of the library's tune_print (tests, tools/cfg_selections.py)
 
 
