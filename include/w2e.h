@@ -160,6 +160,7 @@ int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch
  *   version 2 (the one the host uses): persistent workgroups of 4 matrix + 4 loader waves; K a power of two >= 32; the fused dot is
  *     NOT accumulated: dot_out receives one partial per (channel, spatial block), [batch][N][H/16 * W/32] floats (written, no
  *     atomics: deterministic), which the caller sums over the last axis (w2e_channel_sums).  wgs > 0 caps the persistent grid (tests).
+ *   version 3: version 2 with the raw patch staged by LDS-DMA (three chunks in flight, explicit waits); K <= 256; otherwise as version 2.
  *   version 1: one workgroup per block, N = 32 or 64, any K % 8 == 0; dot_out [B,N] accumulated with atomics. */
 int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void* stream);
 int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const float* out_scale, float* y, int batch, int k_ch,

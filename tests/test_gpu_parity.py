@@ -1003,7 +1003,9 @@ def test_modconv_pipelined_kernel(b, k, n, h, w, wgs, w2e_opt):
                                          (4, 3, 64, 48, 16, 16), (4, 1, 24, 40, 32, 32), (4, 2, 512, 512, 32, 32), (4, 5, 16, 16, 64, 32),
                                          (4, 2, 128, 128, 16, 32),
                                          (8, 2, 32, 32, 32, 64), (8, 1, 64, 64, 16, 32), (8, 3, 128, 32, 48, 32), (8, 2, 64, 32, 32, 32), (8, 5, 32, 64, 64, 64),
-                                         (8, 2, 32, 128, 32, 32), (9, 3, 40, 32, 48, 32), (9, 2, 32, 64, 32, 64)])
+                                         (8, 2, 32, 128, 32, 32), (9, 3, 40, 32, 48, 32), (9, 2, 32, 64, 32, 64),
+                                         (10, 2, 32, 32, 32, 64), (10, 1, 64, 64, 16, 32), (10, 3, 128, 32, 48, 32), (10, 5, 32, 64, 64, 64),
+                                         (10, 2, 32, 128, 32, 32), (10, 1, 32, 32, 64, 96)])
 def test_modconv_winograd_form(m, b, k, n, h, w):
     """K1w: the Winograd forms F(2x2,3x3) and F(4x4,3x3) of the same-resolution conv (w2e_wino_weights / _input / _output around one
     strided-batched fp32 GEMM) against float64 convolutions, every epilogue of w2e_modconv3x3 -- plain, unmodulated, noise + bias +
@@ -1032,8 +1034,8 @@ def test_modconv_winograd_form(m, b, k, n, h, w):
     xdot = torch.randn(b, k, h, w, generator=g).to(DEV)
     graw = F.conv_transpose2d(gy.double() * so, wd, padding=1)
     saved, saved_f = K.WINOGRAD, (K.FUSED_VERSION, K.FUSED_WGS)
-    if m >= 8:
-        K.FUSED_VERSION, K.FUSED_WGS = (2, 3) if m == 8 else (1, 0)
+    if m >= 8:  # 8: version 2, 9: version 1, 10: version 3 (the patch by LDS-DMA); 3 workgroups: several blocks each
+        K.FUSED_VERSION, K.FUSED_WGS = {8: (2, 3), 9: (1, 0), 10: (3, 3)}[m]
         m = 8
     try:
         K.set_winograd(False)

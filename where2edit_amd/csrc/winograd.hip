@@ -736,6 +736,272 @@ __global__ __launch_bounds__(512, 1) void wino4_fused2_kernel(const float* __res
     }
 }
 
+
+// ------------------------------------------------------------------ F(4x4, 3x3), fused, persistent, patch staged by LDS-DMA
+// Version 3: the structure of wino4_fused2_kernel (4 matrix waves + 4 transform waves in lock-step ticks, persistent over blocks), with
+// the input no longer fetched window by window into registers.  The transform waves stage the RAW 8-channel patch of a block --
+// [8 ch][18 rows][10 quads] floats, image columns bx*32-4 .. bx*32+35 so that every 16-byte quad is either wholly inside the image
+// row or wholly outside it (zero padding = an out-of-range offset, exact) -- by `buffer_load_dwordx4 ... lds` into a ring of three
+// stages, three chunks ahead of the MFMAs, with explicit vmcnt counts: no registers, no compiler-managed waits, 6 DMA instructions per
+// wave and chunk instead of 18 window loads per thread.  A transform thread reads its 6x6 window from the stage (one ds_read_b128 +
+// two ds_read_b32 per row).  Per block: a pre-tick (chunk 0 -> V[0]), KC matrix ticks (MFMAs of chunk c | transform of chunk c+1,
+// DMA of chunk g+3), then two output rounds of 16 channels through the V space, in which all 512 threads own a (channel, tile) pair.
+template <int ACT, bool DOT>
+__global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                                                              const float* __restrict__ uf, const float* __restrict__ out_scale,
+                                                              float* __restrict__ y, int B, int K, int N, int H, int W, int kc_log2,
+                                                              int n_blocks, const float* __restrict__ noise,
+                                                              const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                              const float* __restrict__ slope, const float* __restrict__ dot_with,
+                                                              float* __restrict__ dot_partial) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    constexpr int VS = 36 * 2 * 32 * 4;   // floats of one V stage; the two stages together are the output buffer M[36][16][32]
+    constexpr int PQ = 8 * 18 * 10;       // quads of one patch chunk
+    constexpr int PS = 24 * 64 * 4;       // floats of one ring stage: 24 wave-instructions x 64 lanes x 16 B (>= PQ quads)
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // V[2][VS], ring[3][PS], in_scale table [2][256]
+    float* const mbuf = wsm;
+    float* const ring = wsm + 2 * VS;
+    float* const sctab = ring + 3 * PS;  // in_scale[b, .] of the current / the next block, written by the matrix waves: the transform
+                                         // waves issue no compiler-managed global load inside their tick loop (its wait would be vmcnt(0)
+                                         // and drain the DMA ring)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx_n = W >> 5, by_n = H >> 4, per_img = bx_n * by_n;
+    const int KC = 1 << kc_log2;
+    const int count = (n_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = count << kc_log2;
+    const int n0 = blockIdx.y * 32;
+    const int oj = tid & 31, on16 = tid >> 5;
+    const float nw = (ACT == 1 && noise) ? noise_w[0] : 0.f;
+    struct OutPre {
+        float4 nz[4];
+        float os, bs, sl;
+    };
+    auto out_prefetch = [&](OutPre& pre, int b, int64_t opix, int n) __attribute__((always_inline)) {
+        const int64_t plane = (int64_t)b * N + n;
+        pre.os = out_scale ? out_scale[plane] : 1.f;
+        pre.bs = (ACT && bias) ? bias[n] : 0.f;
+        pre.sl = (ACT == 2 && slope) ? slope[n] : 1.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            pre.nz[ii] = (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + opix + (int64_t)ii * W) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto out_items = [&](const OutPre& pre, int blk, int b, int64_t opix, int n) __attribute__((always_inline)) {
+        const float* mp = mbuf + on16 * 32 + oj;
+        float s[4][6];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            float col[6];
+#pragma unroll
+            for (int ii = 0; ii < 6; ++ii) col[ii] = mp[(ii * 6 + jj) * 512];
+            float o[4];
+            wino4_at(col, o);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) s[ii][jj] = o[ii];
+        }
+        const int64_t plane = (int64_t)b * N + n;
+        float part = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            float o[4];
+            wino4_at(s[ii], o);
+            if (DOT) {
+                const float4 d = *reinterpret_cast<const float4*>(dot_with + plane * H * W + opix + (int64_t)ii * W);
+                part += (o[0] * d.x + o[1] * d.y) + (o[2] * d.z + o[3] * d.w);
+            }
+            float4 r = make_float4(o[0] * pre.os, o[1] * pre.os, o[2] * pre.os, o[3] * pre.os);
+            if (ACT == 1) {
+                const float4 nz = pre.nz[ii];
+                r.x += nw * nz.x + pre.bs, r.y += nw * nz.y + pre.bs, r.z += nw * nz.z + pre.bs, r.w += nw * nz.w + pre.bs;
+                r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
+                r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
+            }
+            if (ACT == 2) {
+                r.x += pre.bs, r.y += pre.bs, r.z += pre.bs, r.w += pre.bs;
+                r.x = r.x > 0.f ? r.x : pre.sl * r.x, r.y = r.y > 0.f ? r.y : pre.sl * r.y;
+                r.z = r.z > 0.f ? r.z : pre.sl * r.z, r.w = r.w > 0.f ? r.w : pre.sl * r.w;
+            }
+            *reinterpret_cast<float4*>(y + plane * H * W + opix + (int64_t)ii * W) = r;
+        }
+        if (DOT) {  // one partial per (channel, spatial block of the image), summed by the caller
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (oj == 0) dot_partial[((int64_t)b * N + n) * per_img + (blk - b * per_img)] = part;
+        }
+    };
+    auto block_pix = [&](int blk, int& b, int64_t& opix) __attribute__((always_inline)) {
+        b = blk / per_img;
+        const int rem = blk - b * per_img;
+        const int by = rem / bx_n, bx = rem - by * bx_n;
+        opix = (int64_t)(by * 16 + 4 * (oj >> 3)) * W + bx * 32 + 4 * (oj & 7);
+    };
+    if (wave >= 4) {
+        // ---------------------------------------------------------------------------------------------- transform waves
+        const int tw = wave - 4;
+        const int tj = tid & 31, tch = (tid >> 5) & 7;  // tile of a block, channel of a chunk
+        const uint64_t a64 = (uint64_t)(uintptr_t)x;
+        i32x4 qx;
+        qx[0] = (int)(unsigned)a64, qx[1] = (int)(unsigned)((a64 >> 32) & 0xffffu), qx[2] = (int)(unsigned)((int64_t)B * K * H * W * 4), qx[3] = 0x00020000;
+        qx[0] = __builtin_amdgcn_readfirstlane(qx[0]), qx[1] = __builtin_amdgcn_readfirstlane(qx[1]);
+        qx[2] = __builtin_amdgcn_readfirstlane(qx[2]), qx[3] = __builtin_amdgcn_readfirstlane(qx[3]);
+        const unsigned lds_ring = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+        const unsigned plane_bytes = (unsigned)(H * W) * 4u;
+        // this lane's quad of each of its wave's 6 DMA instructions: qd = (tw*6 + s)*64 + lane -> (channel, patch row, quad)
+        int q_ch[6], q_row[6], q_q[6];
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+            const int qd = (tw * 6 + s6) * 64 + lane;
+            q_ch[s6] = qd < PQ ? qd / 180 : -1;
+            const int rem = qd - (qd / 180) * 180;
+            q_row[s6] = rem / 10, q_q[s6] = rem - (rem / 10) * 10;
+        }
+        unsigned voff[6];  // byte offsets inside the image (b) of the block being ISSUED, or the out-of-range marker
+        int voff_blk = -1;
+        auto set_voff = [&](int bi) __attribute__((always_inline)) {
+            const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+            const int b = blk / per_img, rem = blk - b * per_img;
+            const int by = rem / bx_n, bx = rem - by * bx_n;
+            (void)b;
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int iy = by * 16 - 1 + q_row[s6], ix = bx * 32 - 4 + 4 * q_q[s6];
+                const bool ok = q_ch[s6] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                voff[s6] = ok ? (unsigned)q_ch[s6] * plane_bytes + (unsigned)(iy * W + ix) * 4u : 0xfffffff0u;
+            }
+        };
+        auto issue = [&](int g) __attribute__((always_inline)) {  // DMA of global chunk g into ring stage g % 3
+            const int bi = g >> kc_log2, kc = g & (KC - 1);
+            if (bi != voff_blk) set_voff(bi), voff_blk = bi;
+            const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+            const int b = blk / per_img;
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(b * K + kc * 8) * plane_bytes));
+            const unsigned stage_b = lds_ring + (unsigned)(g % 3) * (unsigned)(PS * 4) + (unsigned)(tw * 6) * 1024u;
+            (void)soff, (void)stage_b;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_b + (unsigned)s6 * 1024u));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff[s6]), "s"(qx), "s"(soff) : "memory");
+            }
+#endif
+        };
+        auto transform = [&](int bi, int kc, int g) __attribute__((always_inline)) {  // chunk (bi, kc) = global g: ring stage g % 3 -> V[kc & 1]
+            const float sc = sctab[(bi & 1) * 256 + kc * 8 + tch];
+            const float* pp = ring + (g % 3) * PS + tch * 720 + (4 * (tj >> 3)) * 40 + 4 * (tj & 7);
+            float t[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const float4 mid = *reinterpret_cast<const float4*>(pp + r * 40 + 4);
+                const float d[6] = {pp[r * 40 + 3], mid.x, mid.y, mid.z, mid.w, pp[r * 40 + 8]};
+                wino4_bt(d, t[r]);
+            }
+            float* vp = wsm + (kc & 1) * VS + ((tch & 1) * 32 + tj) * 4 + (tch >> 1);
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                const float col[6] = {t[0][jj], t[1][jj], t[2][jj], t[3][jj], t[4][jj], t[5][jj]};
+                float o[6];
+                wino4_bt(col, o);
+#pragma unroll
+                for (int i6 = 0; i6 < 6; ++i6) vp[(i6 * 6 + jj) * 256] = sc * o[i6];
+            }
+        };
+        // prologue: chunks 0, 1, 2 on their way; 0 and 1 landed
+        issue(0);
+        if (1 < total) issue(1);
+        if (2 < total) issue(2);
+        if (2 < total) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): chunk 2 may still fly
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        for (int i = 0; i < count; ++i) {
+            const int g0 = i << kc_log2;
+            transform(i, 0, g0);  // pre-tick
+            __syncthreads();
+            for (int c = 0; c < KC; ++c) {
+                const int g = g0 + c;
+                const bool more = g + 3 < total;
+                if (more) issue(g + 3);  // (its stage held chunk g, transformed one tick ago)
+                if (c + 1 < KC) transform(i, c + 1, g + 1);
+                if (more) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): everything but the chunk just issued has landed
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+            }
+            const int blk = (int)blockIdx.x + i * (int)gridDim.x;
+            int b;
+            int64_t opix;
+            block_pix(blk, b, opix);
+            OutPre pre;
+            out_prefetch(pre, b, opix, n0 + on16);
+            __syncthreads();  // A0
+            out_items(pre, blk, b, opix, n0 + on16);
+            out_prefetch(pre, b, opix, n0 + 16 + on16);
+            __syncthreads();  // B0
+            __syncthreads();  // A1
+            out_items(pre, blk, b, opix, n0 + 16 + on16);
+            __syncthreads();  // B1
+        }
+        return;
+    }
+    // -------------------------------------------------------------------------------------------------- matrix waves
+    const int half = lane >> 5, j = lane & 31;
+    const int g = wave;
+    wf_f32x16 acc[9];
+    const float4* uf4 = reinterpret_cast<const float4*>(uf);
+    float4 a[9];  // A operands, loaded one tick ahead and in place (wino4_fused2_kernel)
+    auto a_at = [&](int q, int kc) __attribute__((always_inline)) {
+        return uf4[((((int64_t)(9 * g + q) << kc_log2) + kc) * 2 + half) * N + n0 + j];
+    };
+    auto mfma_tick = [&](int stage, int next_kc) __attribute__((always_inline)) {
+        const float4* vs4 = reinterpret_cast<const float4*>(wsm + stage * VS);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const float4 b4 = vs4[((9 * g + q) * 2 + half) * 32 + j];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b4.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b4.y, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b4.z, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b4.w, acc[q], 0, 0, 0);
+            a[q] = a_at(q, next_kc);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = a_at(q, 0);
+    auto fill_sctab = [&](int bi) __attribute__((always_inline)) {  // in_scale[b, 0..K) of block number bi (K <= 256)
+        if (bi >= count) return;
+        const int b = ((int)blockIdx.x + bi * (int)gridDim.x) / per_img;
+        if (tid < K) sctab[(bi & 1) * 256 + tid] = in_scale ? in_scale[(int64_t)b * K + tid] : 1.f;
+    };
+    fill_sctab(0);
+    __syncthreads();  // (prologue)
+    for (int i = 0; i < count; ++i) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        __syncthreads();  // pre-tick
+        for (int c = 0; c < KC; ++c) {
+            mfma_tick(c & 1, (c + 1) & (KC - 1));
+            __syncthreads();
+        }
+        const int blk = (int)blockIdx.x + i * (int)gridDim.x;
+        int b;
+        int64_t opix;
+        block_pix(blk, b, opix);
+        OutPre pre;
+        fill_sctab(i + 1);  // (the last transform of block i was one tick ago; the table of block i+1 is read from its pre-tick on)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {  // (unrolled: the accumulator registers are indexed by q2)
+            out_prefetch(pre, b, opix, n0 + 16 * q2 + on16);
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    mbuf[((9 * g + q) * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * half) * 32 + j] = acc[q][8 * q2 + rr];
+            __syncthreads();  // A
+            out_items(pre, blk, b, opix, n0 + 16 * q2 + on16);
+            __syncthreads();  // B
+        }
+    }
+}
+
 }  // namespace w2e
 
 using namespace w2e;
@@ -821,7 +1087,7 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
                    const float* dot_with, float* dot_out, int version, int wgs, void* stream) {
     W2E_REQUIRE(x && uf && y, "wino_fused: null tensor");
     W2E_REQUIRE(act >= 0 && act <= 2, "wino_fused: epilogue %d (0 none, 1 StyledConv, 2 bias + PReLU)", act);
-    W2E_REQUIRE(version == 1 || version == 2, "wino_fused: version %d (1 or 2)", version);
+    W2E_REQUIRE(version >= 1 && version <= 3, "wino_fused: version %d (1, 2 or 3)", version);
     W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && n_ch > 0 && (n_ch & 31) == 0, "wino_fused: K %% 8 == 0, N %% 32 == 0 (got %d, %d)", k_ch, n_ch);
     W2E_REQUIRE(h >= 16 && w >= 32 && (h & 15) == 0 && (w & 31) == 0, "wino_fused: H %% 16 == 0 and W %% 32 == 0 (got %d x %d)", h, w);
     W2E_REQUIRE(!(act && dot_with), "wino_fused: the activation epilogues and the fused dot exclude each other");
@@ -836,7 +1102,7 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
     W2E_REQUIRE(blocks < ((int64_t)1 << 31), "wino_fused: too many tile blocks");
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = (unsigned)blocks;
-    if (version == 2) {  // persistent, specialised waves: K a power of two >= 16; the fused dot leaves [blocks][N] partials
+    if (version == 2 || version == 3) {  // persistent, specialised waves: K a power of two >= 32; the fused dot leaves per-block partials
         W2E_REQUIRE(k_ch >= 32 && (k_ch & (k_ch - 1)) == 0, "wino_fused v2: K must be a power of two >= 32 (got %d)", k_ch);
         W2E_REQUIRE((int64_t)batch * k_ch * h * w * 4 < ((int64_t)1 << 32) - 64, "wino_fused v2: x exceeds 4 GB");
         int kc_log2 = 0;
@@ -853,6 +1119,24 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
         if (gx > blocks) gx = (int)blocks;
         if ((wgs & 0xffff) > 0 && (wgs & 0xffff) < gx) gx = wgs & 0xffff;  // (tests: several blocks per workgroup on small inputs; bits 16+: a tuning build's skip mask)
         const dim3 g2((unsigned)gx, (unsigned)nby);
+        if (version == 3) {
+            W2E_REQUIRE(k_ch <= 256, "wino_fused v3: K <= 256 (got %d)", k_ch);
+            const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256) * 4;
+            static unsigned done3[4];
+#define W2E_WF3(ACTv, DOTv, slot)                                                                                                          \
+    do {                                                                                                                                   \
+        W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv>, &done3[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
+        wino4_fused3_kernel<ACTv, DOTv><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
+                                                             noise, noise_w, bias, slope, dot_with, dot_out);                              \
+    } while (0)
+            if (act == 1) W2E_WF3(1, false, 0);
+            else if (act == 2) W2E_WF3(2, false, 1);
+            else if (dot_with) W2E_WF3(0, true, 2);
+            else W2E_WF3(0, false, 3);
+#undef W2E_WF3
+            W2E_LAUNCH_CHECK("wino_fused (v3)");
+            return 0;
+        }
         const size_t lds2 = (size_t)4 * 36 * 2 * 32 * 4 * 4;
         static unsigned done2[4];
 #define W2E_WF2(ACTv, DOTv, slot)                                                                                                          \

@@ -249,8 +249,8 @@ MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 # direct kernel's epilogues.  WINOGRAD (W2E_WINOGRAD, read once here):
 #   "auto"  per layer, what measures fastest (profiles/r03_winograd.txt): F(4x4,3x3) for K, N >= 128 at 16^2 ... 256^2 -- its
 #           transform-domain tensors are 2.25x the input / output and its GEMMs a quarter of the direct FLOPs; batch 8: 512 -> 512 @ 64^2
-#           1.05 -> WINO_64 ms, 256 -> 256 @ 128^2 1.07 -> WINO_128, 128 -> 128 @ 256^2 1.10 -> WINO_256; 64 -> 64 @ 512^2 stays direct
-#           (1.16 ms against 0.64 for the GEMMs alone plus 3.5 GB of transform traffic).  Rounding ~1e-5 relative (direct: 3e-7)
+#           1.05 -> 0.39 ms, 256 -> 256 @ 128^2 1.07 -> 0.48; the FUSED kernel (w2e_wino_fused: nothing transform-domain in HBM) for
+#           128 @ 256^2 (1.10 -> 0.62), 64 @ 512^2 (1.16 -> 0.72) and 32 @ 1024^2 (1.29 -> 0.98).  Rounding ~1e-5 relative (direct: 3e-7)
 #   "f2"    F(2x2,3x3) wherever it beats the direct kernel (K, N >= 256 at 16^2 ... 128^2): rounding 6e-7, about half of "auto"'s gain
 #   False   direct kernels only ("0");  2 / 4: that form wherever the shapes allow (tests)
 WINOGRAD = {"0": False, "2": 2, "4": 4, "8": 8, "f2": "f2"}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
@@ -268,21 +268,23 @@ def set_winograd(mode):
     WINOGRAD = mode
 
 
-FUSED_VERSION = "auto"  # 1: one workgroup per 32-tile block (N = 32 / 64; atomics for the fused dot); 2: persistent, loader + matrix waves
-#                          (K a power of two >= 32, the fused dot as per-block partials); "auto": 1 for the forward epilogues (faster there:
-#                          64 -> 64 @ 512^2 batch 8 0.82 vs 0.90 ms), 2 for the input-gradient pass (0.47 vs 0.57 ms at batch 4: no atomics)
-FUSED_WGS = 0           # > 0: cap of version 2's persistent grid (tests)
+FUSED_VERSION = "auto"  # the fused kernel's variants (include/w2e.h): 1 one workgroup per 32-tile block (N = 32 / 64; atomics for the fused dot);
+#                          2 persistent, loader + matrix waves (K a power of two >= 32; the fused dot as per-block partials); 3 = 2 with the raw
+#                          patch staged by LDS-DMA (K <= 256).  "auto": 3 where its shapes allow (32 @ 1024^2, batch 8 forward: 0.98 ms against
+#                          1.19 / 1.18 for 1 / 2 and 1.28 direct; 64 @ 512^2: 0.72 / 0.81 / 0.89 / 1.15), else 1, else 2
+FUSED_WGS = 0           # > 0: cap of the persistent grid of versions 2 / 3 (tests)
 
 
 def _fused_version(k, n, dot):
     v1_ok, v2_ok = n in (32, 64), (k >= 32 and k & (k - 1) == 0)
+    v3_ok = v2_ok and k <= 256
     if FUSED_VERSION == 1:
         return 1 if v1_ok else 0
     if FUSED_VERSION == 2:
         return 2 if v2_ok else 0
-    if dot:
-        return 2 if v2_ok else (1 if v1_ok else 0)
-    return 1 if v1_ok else (2 if v2_ok else 0)
+    if FUSED_VERSION == 3:
+        return 3 if v3_ok else 0
+    return 3 if v3_ok else (1 if v1_ok else (2 if v2_ok else 0))
 
 
 def _fused_shape_ok(b, k, n, h, w, dot=False):
@@ -305,8 +307,8 @@ def _wino_form(x, k, n, h, w, dot_with):
     b = x.shape[0]
     if WINOGRAD == "auto":
         m = 4 if (k >= 128 and n >= 128 and 16 <= h <= 256 and 16 <= w <= 256) else 0
-        if not m and k <= 64 and n <= 64 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w, dot_with is not None):
-            m = FUSED  # the 64- and 32-channel layers at 512^2 / 1024^2
+        if k <= 128 and n <= 128 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w, dot_with is not None):
+            m = FUSED  # 128 @ 256^2 (0.62 ms fused against 0.70 through the GEMM), 64 @ 512^2, 32 @ 1024^2
     elif WINOGRAD == "f2":
         m = 2 if (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128) else 0
     else:
@@ -318,7 +320,7 @@ def _wino_form(x, k, n, h, w, dot_with):
         return 0
     if _lib.get_option("conv_precision") != 0:
         return 0
-    if dot_with is not None and not (m == FUSED and _fused_version(k, n, True) == 2) and _lib.get_option("deterministic"):
+    if dot_with is not None and not (m == FUSED and _fused_version(k, n, True) >= 2) and _lib.get_option("deterministic"):
         return 0  # (their fused dot uses atomics; the fused kernel's partials are summed in a fixed order)
     return m if _lib.get_option("tune_cfg") < 0 else 0  # (a forced direct tile: tests, tools/layer_bench.py)
 
@@ -353,11 +355,11 @@ def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, d
         if act is not None:
             noise, noise_w, bias = act
         ver = _fused_version(k, n, dot_with is not None)
-        if dot_with is not None and ver == 2:  # one partial per (spatial block, channel): summed here, in a fixed order
+        if dot_with is not None and ver >= 2:  # one partial per (spatial block, channel): summed here, in a fixed order
             nblk = (h // 16) * (w // 32)
             part = torch.empty((b, n, nblk), device=x.device, dtype=torch.float32)
             call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
-                 0, None, None, None, None, ptr(dot_with), ptr(part), 2, FUSED_WGS, stream_ptr())
+                 0, None, None, None, None, ptr(dot_with), ptr(part), ver, FUSED_WGS, stream_ptr())
             sums = torch.empty((b, n), device=x.device, dtype=torch.float32)  # (a kernel, not aten::sum: that one memsets under capture)
             call("w2e_channel_sums", ptr(part), None, ptr(sums), b, n, nblk, stream_ptr())
             dot.add_(sums)
