@@ -753,7 +753,10 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
                                                               int n_blocks, const float* __restrict__ noise,
                                                               const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                               const float* __restrict__ slope, const float* __restrict__ dot_with,
-                                                              float* __restrict__ dot_partial) {
+                                                              float* __restrict__ dot_partial, int skip) {
+#ifndef W2E_TUNING
+    skip = 0;  // (tuning builds only: bit 0 no DMA after the prologue's, 1 no transform, 2 no MFMAs, 3 no output rounds)
+#endif
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     constexpr int VS = 36 * 2 * 32 * 4;   // floats of one V stage; the two stages together are the output buffer M[36][16][32]
     constexpr int PQ = 8 * 18 * 10;       // quads of one patch chunk
@@ -762,8 +765,9 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     float* const mbuf = wsm;
     float* const ring = wsm + 2 * VS;
     float* const sctab = ring + 3 * PS;  // in_scale[b, .] of the current / the next block, written by the matrix waves: the transform
-                                         // waves issue no compiler-managed global load inside their tick loop (its wait would be vmcnt(0)
-                                         // and drain the DMA ring)
+                                         // waves issue no compiler-managed global load at all (its wait would be vmcnt(0) and drain the
+                                         // DMA ring) -- the epilogue operands come the same way:
+    float* const etab = sctab + 512;     // the block's noise patch [16][32], then out_scale / bias / slope of the 32 channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx_n = W >> 5, by_n = H >> 4, per_img = bx_n * by_n;
@@ -773,21 +777,10 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     const int n0 = blockIdx.y * 32;
     const int oj = tid & 31, on16 = tid >> 5;
     const float nw = (ACT == 1 && noise) ? noise_w[0] : 0.f;
-    struct OutPre {
-        float4 nz[4];
-        float os, bs, sl;
-    };
-    auto out_prefetch = [&](OutPre& pre, int b, int64_t opix, int n) __attribute__((always_inline)) {
-        const int64_t plane = (int64_t)b * N + n;
-        pre.os = out_scale ? out_scale[plane] : 1.f;
-        pre.bs = (ACT && bias) ? bias[n] : 0.f;
-        pre.sl = (ACT == 2 && slope) ? slope[n] : 1.f;
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-            pre.nz[ii] = (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + opix + (int64_t)ii * W) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto out_items = [&](const OutPre& pre, int blk, int b, int64_t opix, int n) __attribute__((always_inline)) {
-        const float* mp = mbuf + on16 * 32 + oj;
+    auto out_items = [&](int blk, int b, int64_t opix, int nloc) __attribute__((always_inline)) {  // nloc: channel within the block of 32
+        const int n = n0 + nloc;
+        const float os = etab[512 + nloc], bs = etab[544 + nloc], sl = etab[576 + nloc];
+        const float* mp = mbuf + (nloc & 15) * 32 + oj;
         float s[4][6];
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj) {
@@ -809,17 +802,17 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
                 const float4 d = *reinterpret_cast<const float4*>(dot_with + plane * H * W + opix + (int64_t)ii * W);
                 part += (o[0] * d.x + o[1] * d.y) + (o[2] * d.z + o[3] * d.w);
             }
-            float4 r = make_float4(o[0] * pre.os, o[1] * pre.os, o[2] * pre.os, o[3] * pre.os);
+            float4 r = make_float4(o[0] * os, o[1] * os, o[2] * os, o[3] * os);
             if (ACT == 1) {
-                const float4 nz = pre.nz[ii];
-                r.x += nw * nz.x + pre.bs, r.y += nw * nz.y + pre.bs, r.z += nw * nz.z + pre.bs, r.w += nw * nz.w + pre.bs;
+                const float4 nz = *reinterpret_cast<const float4*>(etab + (4 * (oj >> 3) + ii) * 32 + 4 * (oj & 7));
+                r.x += nw * nz.x + bs, r.y += nw * nz.y + bs, r.z += nw * nz.z + bs, r.w += nw * nz.w + bs;
                 r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
                 r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
             }
             if (ACT == 2) {
-                r.x += pre.bs, r.y += pre.bs, r.z += pre.bs, r.w += pre.bs;
-                r.x = r.x > 0.f ? r.x : pre.sl * r.x, r.y = r.y > 0.f ? r.y : pre.sl * r.y;
-                r.z = r.z > 0.f ? r.z : pre.sl * r.z, r.w = r.w > 0.f ? r.w : pre.sl * r.w;
+                r.x += bs, r.y += bs, r.z += bs, r.w += bs;
+                r.x = r.x > 0.f ? r.x : sl * r.x, r.y = r.y > 0.f ? r.y : sl * r.y;
+                r.z = r.z > 0.f ? r.z : sl * r.z, r.w = r.w > 0.f ? r.w : sl * r.w;
             }
             *reinterpret_cast<float4*>(y + plane * H * W + opix + (int64_t)ii * W) = r;
         }
@@ -914,13 +907,13 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         __syncthreads();
         for (int i = 0; i < count; ++i) {
             const int g0 = i << kc_log2;
-            transform(i, 0, g0);  // pre-tick
+            if (!(skip & 2)) transform(i, 0, g0);  // pre-tick
             __syncthreads();
             for (int c = 0; c < KC; ++c) {
                 const int g = g0 + c;
-                const bool more = g + 3 < total;
+                const bool more = g + 3 < total && !(skip & 1);
                 if (more) issue(g + 3);  // (its stage held chunk g, transformed one tick ago)
-                if (c + 1 < KC) transform(i, c + 1, g + 1);
+                if (c + 1 < KC && !(skip & 2)) transform(i, c + 1, g + 1);
                 if (more) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): everything but the chunk just issued has landed
                 else __builtin_amdgcn_s_waitcnt(0x0F70);
                 __syncthreads();
@@ -929,14 +922,13 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             int b;
             int64_t opix;
             block_pix(blk, b, opix);
-            OutPre pre;
-            out_prefetch(pre, b, opix, n0 + on16);
+            // (with the fused dot an item loads 16 floats of dot_with from global memory: a compiler-managed wait that drains this wave's
+            // DMA ring once per block; leaving all items to the matrix waves instead measured slower: 1.04 vs 0.98 ms, 32 @ 1024^2 batch 8)
             __syncthreads();  // A0
-            out_items(pre, blk, b, opix, n0 + on16);
-            out_prefetch(pre, b, opix, n0 + 16 + on16);
+            if (!(skip & 8)) out_items(blk, b, opix, on16);
             __syncthreads();  // B0
             __syncthreads();  // A1
-            out_items(pre, blk, b, opix, n0 + 16 + on16);
+            if (!(skip & 8)) out_items(blk, b, opix, 16 + on16);
             __syncthreads();  // B1
         }
         return;
@@ -969,6 +961,22 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         const int b = ((int)blockIdx.x + bi * (int)gridDim.x) / per_img;
         if (tid < K) sctab[(bi & 1) * 256 + tid] = in_scale ? in_scale[(int64_t)b * K + tid] : 1.f;
     };
+    auto fill_etab = [&](int bi) __attribute__((always_inline)) {  // noise patch and per-channel epilogue operands of block number bi
+        const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+        const int b = blk / per_img, rem = blk - b * per_img;
+        const int by = rem / bx_n, bx = rem - by * bx_n;
+        if (tid < 128) {
+            const int row = tid >> 3, qd = tid & 7;
+            *reinterpret_cast<float4*>(etab + row * 32 + 4 * qd) =
+                (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + (int64_t)(by * 16 + row) * W + bx * 32 + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (tid < 160) {
+            etab[512 + tid - 128] = out_scale ? out_scale[(int64_t)b * N + n0 + tid - 128] : 1.f;
+        } else if (tid < 192) {
+            etab[544 + tid - 160] = (ACT && bias) ? bias[n0 + tid - 160] : 0.f;
+        } else if (tid < 224) {
+            etab[576 + tid - 192] = (ACT == 2 && slope) ? slope[n0 + tid - 192] : 1.f;
+        }
+    };
     fill_sctab(0);
     __syncthreads();  // (prologue)
     for (int i = 0; i < count; ++i) {
@@ -976,27 +984,28 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         for (int q = 0; q < 9; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        fill_etab(i);     // (the previous block's output rounds are behind the last barrier; this block's come KC ticks later)
         __syncthreads();  // pre-tick
         for (int c = 0; c < KC; ++c) {
-            mfma_tick(c & 1, (c + 1) & (KC - 1));
+            if (!(skip & 4)) mfma_tick(c & 1, (c + 1) & (KC - 1));
             __syncthreads();
         }
         const int blk = (int)blockIdx.x + i * (int)gridDim.x;
         int b;
         int64_t opix;
         block_pix(blk, b, opix);
-        OutPre pre;
         fill_sctab(i + 1);  // (the last transform of block i was one tick ago; the table of block i+1 is read from its pre-tick on)
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2) {  // (unrolled: the accumulator registers are indexed by q2)
-            out_prefetch(pre, b, opix, n0 + 16 * q2 + on16);
+            if (!(skip & 8)) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q)
+                for (int q = 0; q < 9; ++q)
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr)
-                    mbuf[((9 * g + q) * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * half) * 32 + j] = acc[q][8 * q2 + rr];
+                    for (int rr = 0; rr < 8; ++rr)
+                        mbuf[((9 * g + q) * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * half) * 32 + j] = acc[q][8 * q2 + rr];
+            }
             __syncthreads();  // A
-            out_items(pre, blk, b, opix, n0 + 16 * q2 + on16);
+            if (!(skip & 8)) out_items(blk, b, opix, 16 * q2 + on16);
             __syncthreads();  // B
         }
     }
@@ -1121,13 +1130,13 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
         const dim3 g2((unsigned)gx, (unsigned)nby);
         if (version == 3) {
             W2E_REQUIRE(k_ch <= 256, "wino_fused v3: K <= 256 (got %d)", k_ch);
-            const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256) * 4;
+            const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256 + 608) * 4;
             static unsigned done3[4];
 #define W2E_WF3(ACTv, DOTv, slot)                                                                                                          \
     do {                                                                                                                                   \
         W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv>, &done3[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
         wino4_fused3_kernel<ACTv, DOTv><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
-                                                             noise, noise_w, bias, slope, dot_with, dot_out);                              \
+                                                             noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);                   \
     } while (0)
             if (act == 1) W2E_WF3(1, false, 0);
             else if (act == 2) W2E_WF3(2, false, 1);
