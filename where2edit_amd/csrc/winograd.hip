@@ -746,7 +746,8 @@ __global__ __launch_bounds__(512, 1) void wino4_fused2_kernel(const float* __res
 // wave and chunk instead of 18 window loads per thread.  A transform thread reads its 6x6 window from the stage (one ds_read_b128 +
 // two ds_read_b32 per row).  Per block: a pre-tick (chunk 0 -> V[0]), KC matrix ticks (MFMAs of chunk c | transform of chunk c+1,
 // DMA of chunk g+3), then two output rounds of 16 channels through the V space, in which all 512 threads own a (channel, tile) pair.
-template <int ACT, bool DOT>
+// TXN: tiles of a block along x (8: blocks of 32 x 16 pixels; 16: 64 x 8 -- longer row segments per DMA, fewer cache lines per byte).
+template <int ACT, bool DOT, int TXN>
 __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                                               const float* __restrict__ uf, const float* __restrict__ out_scale,
                                                               float* __restrict__ y, int B, int K, int N, int H, int W, int kc_log2,
@@ -759,7 +760,10 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
 #endif
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     constexpr int VS = 36 * 2 * 32 * 4;   // floats of one V stage; the two stages together are the output buffer M[36][16][32]
-    constexpr int PQ = 8 * 18 * 10;       // quads of one patch chunk
+    constexpr int TYN = 32 / TXN, BWP = 4 * TXN, BHP = 4 * TYN;  // tiles along y; block width / height in pixels
+    constexpr int PR = BHP + 2, PC = BWP + 8, QR = PC / 4;        // patch rows, columns (image columns bx*BWP-4 ...), quads per row
+    constexpr int PQ = 8 * PR * QR;       // quads of one patch chunk (1440 for both shapes)
+    static_assert(PR * PC == 720 && PQ <= 24 * 64, "patch geometry");
     constexpr int PS = 24 * 64 * 4;       // floats of one ring stage: 24 wave-instructions x 64 lanes x 16 B (>= PQ quads)
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // V[2][VS], ring[3][PS], in_scale table [2][256]
     float* const mbuf = wsm;
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     float* const etab = sctab + 512;     // the block's noise patch [16][32], then out_scale / bias / slope of the 32 channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bx_n = W >> 5, by_n = H >> 4, per_img = bx_n * by_n;
+    const int bx_n = W / BWP, by_n = H / BHP, per_img = bx_n * by_n;
     const int KC = 1 << kc_log2;
     const int count = (n_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total = count << kc_log2;
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             }
             float4 r = make_float4(o[0] * os, o[1] * os, o[2] * os, o[3] * os);
             if (ACT == 1) {
-                const float4 nz = *reinterpret_cast<const float4*>(etab + (4 * (oj >> 3) + ii) * 32 + 4 * (oj & 7));
+                const float4 nz = *reinterpret_cast<const float4*>(etab + (4 * (oj / TXN) + ii) * BWP + 4 * (oj % TXN));
                 r.x += nw * nz.x + bs, r.y += nw * nz.y + bs, r.z += nw * nz.z + bs, r.w += nw * nz.w + bs;
                 r.x = fmaxf(r.x, 0.2f * r.x) * 1.4142135623730951f, r.y = fmaxf(r.y, 0.2f * r.y) * 1.4142135623730951f;
                 r.z = fmaxf(r.z, 0.2f * r.z) * 1.4142135623730951f, r.w = fmaxf(r.w, 0.2f * r.w) * 1.4142135623730951f;
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         b = blk / per_img;
         const int rem = blk - b * per_img;
         const int by = rem / bx_n, bx = rem - by * bx_n;
-        opix = (int64_t)(by * 16 + 4 * (oj >> 3)) * W + bx * 32 + 4 * (oj & 7);
+        opix = (int64_t)(by * BHP + 4 * (oj / TXN)) * W + bx * BWP + 4 * (oj % TXN);
     };
     if (wave >= 4) {
         // ---------------------------------------------------------------------------------------------- transform waves
@@ -844,9 +848,9 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
 #pragma unroll
         for (int s6 = 0; s6 < 6; ++s6) {
             const int qd = (tw * 6 + s6) * 64 + lane;
-            q_ch[s6] = qd < PQ ? qd / 180 : -1;
-            const int rem = qd - (qd / 180) * 180;
-            q_row[s6] = rem / 10, q_q[s6] = rem - (rem / 10) * 10;
+            q_ch[s6] = qd < PQ ? qd / (PR * QR) : -1;
+            const int rem = qd - (qd / (PR * QR)) * (PR * QR);
+            q_row[s6] = rem / QR, q_q[s6] = rem - (rem / QR) * QR;
         }
         unsigned voff[6];  // byte offsets inside the image (b) of the block being ISSUED, or the out-of-range marker
         int voff_blk = -1;
@@ -857,7 +861,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             (void)b;
 #pragma unroll
             for (int s6 = 0; s6 < 6; ++s6) {
-                const int iy = by * 16 - 1 + q_row[s6], ix = bx * 32 - 4 + 4 * q_q[s6];
+                const int iy = by * BHP - 1 + q_row[s6], ix = bx * BWP - 4 + 4 * q_q[s6];
                 const bool ok = q_ch[s6] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
                 voff[s6] = ok ? (unsigned)q_ch[s6] * plane_bytes + (unsigned)(iy * W + ix) * 4u : 0xfffffff0u;
             }
@@ -880,12 +884,12 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         };
         auto transform = [&](int bi, int kc, int g) __attribute__((always_inline)) {  // chunk (bi, kc) = global g: ring stage g % 3 -> V[kc & 1]
             const float sc = sctab[(bi & 1) * 256 + kc * 8 + tch];
-            const float* pp = ring + (g % 3) * PS + tch * 720 + (4 * (tj >> 3)) * 40 + 4 * (tj & 7);
+            const float* pp = ring + (g % 3) * PS + tch * 720 + (4 * (tj / TXN)) * PC + 4 * (tj % TXN);
             float t[6][6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const float4 mid = *reinterpret_cast<const float4*>(pp + r * 40 + 4);
-                const float d[6] = {pp[r * 40 + 3], mid.x, mid.y, mid.z, mid.w, pp[r * 40 + 8]};
+                const float4 mid = *reinterpret_cast<const float4*>(pp + r * PC + 4);
+                const float d[6] = {pp[r * PC + 3], mid.x, mid.y, mid.z, mid.w, pp[r * PC + 8]};
                 wino4_bt(d, t[r]);
             }
             float* vp = wsm + (kc & 1) * VS + ((tch & 1) * 32 + tj) * 4 + (tch >> 1);
@@ -966,9 +970,9 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         const int b = blk / per_img, rem = blk - b * per_img;
         const int by = rem / bx_n, bx = rem - by * bx_n;
         if (tid < 128) {
-            const int row = tid >> 3, qd = tid & 7;
-            *reinterpret_cast<float4*>(etab + row * 32 + 4 * qd) =
-                (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + (int64_t)(by * 16 + row) * W + bx * 32 + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row = tid / TXN, qd = tid % TXN;
+            *reinterpret_cast<float4*>(etab + row * BWP + 4 * qd) =
+                (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + (int64_t)(by * BHP + row) * W + bx * BWP + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else if (tid < 160) {
             etab[512 + tid - 128] = out_scale ? out_scale[(int64_t)b * N + n0 + tid - 128] : 1.f;
         } else if (tid < 192) {
@@ -1132,11 +1136,19 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
             W2E_REQUIRE(k_ch <= 256, "wino_fused v3: K <= 256 (got %d)", k_ch);
             const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256 + 608) * 4;
             static unsigned done3[4];
+            static unsigned done3w[4];
+            const bool wide = (w & 63) == 0 && !((wgs >> 16) & 16);  // blocks of 64 x 8 pixels (bit 4 of a tuning build's mask: keep 32 x 16)
 #define W2E_WF3(ACTv, DOTv, slot)                                                                                                          \
     do {                                                                                                                                   \
-        W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv>, &done3[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
-        wino4_fused3_kernel<ACTv, DOTv><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
-                                                             noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);                   \
+        if (wide) {                                                                                                                        \
+            W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, 16>, &done3w[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
+            wino4_fused3_kernel<ACTv, DOTv, 16><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
+                                                                     noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);           \
+        } else {                                                                                                                           \
+            W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, 8>, &done3[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
+            wino4_fused3_kernel<ACTv, DOTv, 8><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
+                                                                    noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);            \
+        }                                                                                                                                  \
     } while (0)
             if (act == 1) W2E_WF3(1, false, 0);
             else if (act == 2) W2E_WF3(2, false, 1);
