@@ -237,12 +237,13 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
         assert_close(rep[key], out[key], 1e-5, f"graph replay: {key}")  # (split-K joins by fp32 atomics: run-to-run rounding)
 
 
-@pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 128, 28, 28), (2, 2, 256, 256, 14, 14), (4, 1, 64, 64, 112, 112), (2, 5, 128, 64, 14, 28)])
+@pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 128, 28, 28), (2, 2, 256, 256, 14, 14), (4, 1, 64, 64, 112, 112), (2, 5, 128, 64, 14, 28),
+                                         (8, 2, 64, 64, 32, 64), (8, 3, 128, 256, 16, 32)])
 def test_conv3x3_winograd_forms(m, b, k, n, h, w):
     """The stride-1 convs of the IR-SE50 / e4e encoders through the Winograd forms (w2e_wino_input / one strided-batched GEMM /
     w2e_wino_output with the bias + PReLU epilogue of w2e_conv3x3): forward with BN scale, bias and PReLU, the input-gradient form
     (in_scale on the transposed + flipped pack), against float64 and against the direct kernel; tile counts that are no multiple
-    of 64 (196, 49 per image)."""
+    of 64 (196, 49 per image); m = 8: the fused kernel (w2e_wino_fused version 3) with the same epilogue."""
     import torch.nn.functional as F
     from where2edit_amd import functional as K, irse_hip as I
     g = torch.Generator().manual_seed(5 * k + n + h)
@@ -263,4 +264,6 @@ def test_conv3x3_winograd_forms(m, b, k, n, h, w):
     assert_close(gx, F.conv_transpose2d(gy.double() * a.double()[:, :, None, None], wt.double(), padding=1), 1e-4, "winograd input gradient")
     out = torch.zeros(b + 2, k, h, w, device=DEV)
     I.conv3x3(gy, bwd, k, h, w, in_scale=a, out=out[:b], form=m)
-    assert torch.equal(out[:b], gx) and float(out[b:].abs().max()) == 0.0
+    # (not bit-equal for the GEMM forms: the library's strided-batched GEMM may pick another reduction order for another output address)
+    assert_close(out[:b], gx, 1e-6, "winograd into a view") and float(out[b:].abs().max()) == 0.0
+    assert float(out[b:].abs().max()) == 0.0

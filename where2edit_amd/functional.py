@@ -320,8 +320,9 @@ def _wino_form(x, k, n, h, w, dot_with):
         return 0
     if _lib.get_option("conv_precision") != 0:
         return 0
-    if dot_with is not None and not (m == FUSED and _fused_version(k, n, True) >= 2) and _lib.get_option("deterministic"):
-        return 0  # (their fused dot uses atomics; the fused kernel's partials are summed in a fixed order)
+    if _lib.get_option("deterministic") and not (m == FUSED and _fused_version(k, n, dot_with is not None) >= 2):
+        return 0  # (bit-reproducible mode: the library GEMM of the GEMM forms may reduce in a run-dependent order, and their fused dot
+        #            and version 1's use atomics; the persistent fused kernels sum their partials in a fixed order)
     return m if _lib.get_option("tune_cfg") < 0 else 0  # (a forced direct tile: tests, tools/layer_bench.py)
 
 

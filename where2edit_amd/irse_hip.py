@@ -5,6 +5,8 @@ one-wave-per-plane pooling kernel, a one-workgroup-per-sample gate kernel (fc1 /
 
 Eval mode only (criteria/id_loss.py:14 calls facenet.eval()) and frozen weights: forward + INPUT gradients, which is what
 the identity loss needs (the gradient flows back to the generated image).  One autograd node per bottleneck unit."""
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -37,11 +39,21 @@ def declare(lib):
 
 
 # ---------------------------------------------------------------------------------------------- raw kernel calls
+FUSED_ENCODER = os.environ.get("W2E_FUSED_ENCODER", "1") != "0"  # (A/B aid: the fused Winograd kernel for the encoders' stride-1 convs)
+
+
 def _wino_form(b, k, n, h, w):
     """The Winograd form (functional.py, K1w) of one stride-1 3x3 conv of the IR-SE50 / e4e encoders, or 0: F(4x4,3x3) where the
     image divides into 4x4 tiles, F(2x2,3x3) for the 14^2 stages, the direct kernel for the 64-channel stages, for odd sizes (7^2) and
     where the transform-domain GEMMs are too small to pay for three launches (profiles/r03_irse_shapes.txt)."""
     if K.WINOGRAD is False or K.WINOGRAD == "f2" and (h % 2 or w % 2):
+        return 0
+    # the fused kernel (no transform-domain tensor in HBM, no GEMM call): where its shapes allow, up to 128 input channels it beats
+    # both the direct kernel and the GEMM forms (64 -> 64 @ 256^2, batch 8: 191 us against 350 / 353; 128 -> 256 @ 64^2: 86 / 171 / 114)
+    if FUSED_ENCODER and K.WINOGRAD in ("auto", K.FUSED) and K._fused_shape_ok(b, k, n, h, w) and K._fused_version(k, n, False) == 3 \
+            and (K.WINOGRAD == K.FUSED or (k <= 128 and 18.0 * b * k * n * h * w >= 3e9)):
+        return K.FUSED if (_lib.get_option("conv_precision") == 0 and _lib.get_option("tune_cfg") < 0) else 0
+    if K.WINOGRAD == K.FUSED:
         return 0
     if K.WINOGRAD in (2, 4):
         m = K.WINOGRAD
@@ -55,8 +67,8 @@ def _wino_form(b, k, n, h, w):
         return 0
     if not K._wino_shape_ok(m, b, k, n, h, w, dot=False):
         return 0
-    if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0:
-        return 0
+    if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0 or _lib.get_option("deterministic"):
+        return 0  # (deterministic: the library GEMM may reduce in a run-dependent order)
     return m
 
 
@@ -71,6 +83,12 @@ def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out
             y = out if out is not None else torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
             if out is not None:
                 assert out.shape == (b, n_out, h, w) and out.is_contiguous()
+        if m == K.FUSED:
+            if K.WINO_LOG is not None:
+                K.WINO_LOG.append(f"conv3x3 (winograd F(4x4,3x3) fused v3) K {k} N {n_out} {h}x{w} B {b}")
+            call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(K._wino_weights_fused(wp, k, n_out)), ptr(out_scale), ptr(y), b, k, n_out, h, w,
+                 2 if (bias is not None or slope is not None) else 0, None, None, ptr(bias), ptr(slope), None, None, 3, K.FUSED_WGS, stream_ptr())
+            return y
             tiles = b * (h // m) * (w // m)
             if K.WINO_LOG is not None:
                 K.WINO_LOG.append(f"conv3x3 (winograd F({m}x{m},3x3)) K {k} N {n_out} {h}x{w} B {b} -> {(m + 2) ** 2} x [{n_out}x{k}] x [{k}x{tiles}]")
