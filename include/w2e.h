@@ -157,10 +157,12 @@ int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch
  * W % 32 == 0): input transform, the 36 contractions (fp32 MFMA) and the output transform in ONE kernel -- V and M, 2.25x the
  * input / output each, never leave the CU (through HBM they cost more than the 4x fewer FLOPs return at these sizes).  Same
  * arguments, epilogues and rounding as w2e_wino_output (m = 4) after w2e_wino_input; uf [36][K/8][2][N][4] from w2e_wino_weights_fused.
- *   version 2 (the one the host uses): persistent workgroups of 4 matrix + 4 loader waves; K a power of two >= 32; the fused dot is
+ *   version 2: persistent workgroups of 4 matrix + 4 loader waves; K a power of two >= 32; the fused dot is
  *     NOT accumulated: dot_out receives one partial per (channel, spatial block), [batch][N][H/16 * W/32] floats (written, no
  *     atomics: deterministic), which the caller sums over the last axis (w2e_channel_sums).  wgs > 0 caps the persistent grid (tests).
- *   version 3: version 2 with the raw patch staged by LDS-DMA (three chunks in flight, explicit waits); K <= 256; otherwise as version 2.
+ *   version 3 (the one the host uses): version 2 with the raw patch staged by LDS-DMA (three chunks in flight, explicit waits);
+ *     K <= 256; x must be smaller than 4 GB; otherwise as version 2.  The uniform strided-batched GEMM of the non-fused forms is
+ *     the only step of K1w whose bit-reproducibility is the vendor library's: "deterministic" hosts use versions 2 / 3 or the direct kernels.
  *   version 1: one workgroup per block, N = 32 or 64, any K % 8 == 0; dot_out [B,N] accumulated with atomics. */
 int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void* stream);
 int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const float* out_scale, float* y, int batch, int k_ch,
