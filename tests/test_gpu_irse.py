@@ -255,7 +255,12 @@ def test_conv3x3_winograd_forms(m, b, k, n, h, w):
     pre = F.conv2d(x.double(), wt.double(), padding=1) * a.double()[:, :, None, None] + bias.double()[None, :, None, None]
     ref = torch.where(pre > 0, pre, pre * slope.double()[None, :, None, None])
     y0 = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, slope=slope, form=0)
-    y = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, slope=slope, form=m)
+    K.WINO_LOG = []
+    try:
+        y = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, slope=slope, form=m)
+        assert len(K.WINO_LOG) == 1 and ("fused" in K.WINO_LOG[0]) == (m == 8), K.WINO_LOG  # (the form asked for is the one that ran)
+    finally:
+        K.WINO_LOG = None
     assert_close(y, ref, 1e-4, "winograd conv + BN + PReLU"), assert_close(y, y0, 1e-4, "winograd == direct")
     y = I.conv3x3(x, fwd, n, h, w, out_scale=a, bias=bias, form=m)
     assert_close(y, pre, 1e-4, "winograd conv + BN (no PReLU)")

@@ -33,7 +33,10 @@ for B, Ci, C, H in shapes:
         if H % m == 0:
             t = timeit(lambda: run(m))
             res.append(f"F({m}x{m}) {t:6.1f}us ({flop / t / 1e6:5.1f})")
-    res.append(f"chosen: {I._wino_form(B, Ci, C, H, H) or 'direct'}")
+    if K._fused_shape_ok(B, Ci, C, H, H) and K._fused_version(Ci, C, False) == 3:
+        t = timeit(lambda: run(K.FUSED))
+        res.append(f"fused {t:6.1f}us ({flop / t / 1e6:5.1f})")
+    res.append(f"chosen: {({0: 'direct', K.FUSED: 'fused'}).get(I._wino_form(B, Ci, C, H, H), I._wino_form(B, Ci, C, H, H))}")
     if sweep:
         best = (1e9, None)
         for cfg in range(0, 11):

@@ -89,6 +89,7 @@ def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out
             call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(K._wino_weights_fused(wp, k, n_out)), ptr(out_scale), ptr(y), b, k, n_out, h, w,
                  2 if (bias is not None or slope is not None) else 0, None, None, ptr(bias), ptr(slope), None, None, 3, K.FUSED_WGS, stream_ptr())
             return y
+        if m:
             tiles = b * (h // m) * (w // m)
             if K.WINO_LOG is not None:
                 K.WINO_LOG.append(f"conv3x3 (winograd F({m}x{m},3x3)) K {k} N {n_out} {h}x{w} B {b} -> {(m + 2) ** 2} x [{n_out}x{k}] x [{k}x{tiles}]")
