@@ -301,7 +301,7 @@ def _wino_shape_ok(m, b, k, n, h, w, dot=True):
 
 
 def _wino_form(x, k, n, h, w, dot_with):
-    """0 (direct kernel), 2 or 4 (the F(m x m, 3x3) form) for one W2E_CONV_SAME call."""
+    """0 (direct kernel), 2 or 4 (the F(m x m, 3x3) form through the library GEMM) or FUSED (w2e_wino_fused) for one W2E_CONV_SAME call."""
     if WINOGRAD is False:
         return 0
     b = x.shape[0]
