@@ -1576,6 +1576,7 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     if (opt.tune_print) fprintf(stderr, "modconv mode %d%s K %d N %d %dx%d B %d -> cfg %d splits %d\n", mode, use_all ? " (all-phase)" : "", k_ch, n_ch, h, w, batch, best, best_splits);
     W2E_REQUIRE(best >= 0, "modconv3x3: no tile configuration for N=%d H=%d W=%d", n_ch, h, w);
     const TileCfg cfg = cfgs[best];
+    W2E_REQUIRE(!use_all || cfg.npb >= 4, "modconv3x3: tile %d has no all-phase form (forced by tune_cfg)", best);  // (a forced tile: 0 pixel blocks per phase)
     const int tn = 32 * cfg.nob * cfg.wo, tm = 32 * (use_all ? cfg.npb / 4 : cfg.npb) * cfg.wp;
     p.tw = wp2 < 32 ? wp2 : ((wp2 >= 64 && tm >= 256) ? 64 : 32);
     p.th = tm / p.tw;
