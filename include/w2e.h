@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define W2E_VERSION 3
+#define W2E_VERSION 4
 
 int w2e_version(void);
 const char* w2e_last_error(void);
@@ -75,9 +75,12 @@ int w2e_get_option(const char* name, int* value);
  * enabled when act != 0; out_scale / noise / bias may be NULL (treated as 1 / 0 / 0).
  * in_layout: 0 = x is [planes, in_h, in_w]; 1 = x is the phase-planar image W2E_CONV_UP writes,
  * [planes, 2, 2, (in_h+1)/2, WP] with WP = W2E_PLANAR_PITCH((in_w-1)/2) (sector-aligned rows) and
- * x[Y][X] = x'[Y&1][X&1][Y>>1][X>>1]  (4x4 kernel, up=down=1 only). */
+ * x[Y][X] = x'[Y&1][X&1][Y>>1][X>>1]  (4x4 kernel, up=down=1 only).  in_pitch: the row pitch (floats) the CALLER allocated that
+ * planar image with -- the caller owns the buffer, the kernels index it with W2E_PLANAR_PITCH, so a caller compiled against another
+ * pitch (ABI 2 padded to 4 floats) would hand over a smaller buffer than the kernels read: the call is refused with an error instead
+ * (round 3: a memory access fault in a tool still on the old pitch).  Ignored for in_layout = 0. */
 int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, int in_h, int in_w, int out_h,
-                  int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout,
+                  int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout, int in_pitch,
                   int act, const float* out_scale, const float* noise, const float* noise_w, const float* bias,
                   int channels, float slope, float gain, void* stream);
 /* The StyledConv backward of an up-sampling layer in one pass (op/fused_act.py:42-60 + the adjoint of Blur(pad=(1,1)),
@@ -127,47 +130,52 @@ int w2e_conv_pack(const float* weight, float* wp, int cout, int cin, float scale
  *   act != 0:   y = lrelu(y + noise_w[0]*noise[h,w] + bias[o], 0.2) * sqrt(2)   (SAME only)
  *   dot_with/dot_out: dot_out[b,o] += sum_p conv_unscaled[b,o,p] * dot_with[b,o,p]
  *                     (the direct style gradient sum_p x*g; dot_out must be zeroed by the caller).
- * h,w are the INPUT spatial size for SAME/UP and the OUTPUT size for DOWN. */
+ * h,w are the INPUT spatial size for SAME/UP and the OUTPUT size for DOWN.  y_pitch: for W2E_CONV_UP the row pitch (floats) the
+ * caller allocated the phase-planar y with; anything but W2E_PLANAR_PITCH(w) is refused (see w2e_upfirdn2d's in_pitch); ignored
+ * for SAME / DOWN. */
 int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
-                   float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
+                   float* y, int batch, int k_ch, int n_ch, int h, int w, int y_pitch, int act, const float* noise,
                    const float* noise_w, const float* bias, const float* dot_with, float* dot_out, void* stream);
 
-/* ---- K1w  Winograd forms of W2E_CONV_SAME  (model.py:270-274; the same contract as w2e_modconv3x3) ---------------------
+/* ---- K1w  the FUSED Winograd F(4x4,3x3) form of W2E_CONV_SAME  (model.py:270-274; the same contract as w2e_modconv3x3) -------------
  *     y[b,o] = epilogue(out_scale[b,o] * A^T [ sum_i U[.,o,i] (.) V[.,i,t] ] A)
- * m = 2: F(2x2,3x3), 16 products per 2x2 outputs instead of 36;  m = 4: F(4x4,3x3), 36 per 4x4 outputs instead of 144
- * (interpolation points 0, +-1, +-2, inf).  P = (m+2)^2 transform-domain positions, T = batch * H/m * W/m tiles.
- * Three HBM-bound passes around P plain [N x K] x [K x T] fp32 GEMMs, which the caller runs with the vendor library as ONE
- * strided-batched GEMM  M[P][N][T] = U[P][N][K] x V[P][K][T]  (row-major, fp32):
- *   w2e_wino_weights: packed direct-form weights wp (w2e_conv_pack: any transpose / flip) -> U [P][N][K] = G W G^T; once per pack
- *   w2e_wino_input:   x [B,K,H,W], in_scale [B,K] or NULL -> V [P][K][T] = B^T (in_scale * window) B, zero padding 1; H, W % m == 0
- *   w2e_wino_output:  M [P][N][T], out_scale [B,N] or NULL -> y [B,N,H,W] with the epilogues of w2e_modconv3x3 (act = 1:
- *                     noise_w*noise + bias, LeakyReLU 0.2, sqrt 2; or dot_with / dot_out: dot_out[b,o] += sum_p conv_unscaled *
- *                     dot_with, by fp32 atomics -- not for "deterministic" -- with (H/m)*(W/m) tiles per plane a multiple of 64,
- *                     for m = 4 also a power of two below it) and of w2e_conv3x3 (act = 2: + bias[o], PReLU(slope[o]) if slope).
- * V and M are 4x (m = 2) / 2.25x (m = 4) the input / output bytes: the forms pay where the contraction dominates that traffic
- * (where2edit_amd/functional.py chooses per layer).  Rounding, max-norm relative to a float64 convolution at K = 128 ... 512:
- * direct 3e-7, m = 2 6e-7, m = 4 1e-5 (its transforms multiply by up to 8 and 1/24) -- against the path's 1e-3 tolerance. */
-int w2e_wino_weights(const float* wp, float* u, int k_ch, int n_ch, int m, void* stream);
-int w2e_wino_input(const float* x, const float* in_scale, float* v, int batch, int k_ch, int h, int w, int m, void* stream);
-int w2e_wino_output(const float* mm, const float* out_scale, float* y, int batch, int n_ch, int h, int w, int m, int act,
-                    const float* noise, const float* noise_w, const float* bias, const float* slope, const float* dot_with,
-                    float* dot_out, void* stream);
-
-/* The FUSED F(4x4,3x3) form for the narrow, high-resolution layers (N % 32 == 0 output channels, K % 8 == 0, H % 16 == 0,
- * W % 32 == 0): input transform, the 36 contractions (fp32 MFMA) and the output transform in ONE kernel -- V and M, 2.25x the
- * input / output each, never leave the CU (through HBM they cost more than the 4x fewer FLOPs return at these sizes).  Same
- * arguments, epilogues and rounding as w2e_wino_output (m = 4) after w2e_wino_input; uf [36][K/8][2][N][4] from w2e_wino_weights_fused.
- *   version 2: persistent workgroups of 4 matrix + 4 loader waves; K a power of two >= 32; the fused dot is
- *     NOT accumulated: dot_out receives one partial per (channel, spatial block), [batch][N][H/16 * W/32] floats (written, no
- *     atomics: deterministic), which the caller sums over the last axis (w2e_channel_sums).  wgs > 0 caps the persistent grid (tests).
- *   version 3 (the one the host uses): version 2 with the raw patch staged by LDS-DMA (three chunks in flight, explicit waits);
- *     K <= 256; x must be smaller than 4 GB; otherwise as version 2.  The uniform strided-batched GEMM of the non-fused forms is
- *     the only step of K1w whose bit-reproducibility is the vendor library's: "deterministic" hosts use versions 2 / 3 or the direct kernels.
- *   version 1: one workgroup per block, N = 32 or 64, any K % 8 == 0; dot_out [B,N] accumulated with atomics. */
+ * 36 products per 4x4 outputs instead of 144 (interpolation points 0, +-1, +-2, inf); 36 transform-domain positions, T = batch *
+ * H/4 * W/4 tiles.  For the narrow, high-resolution layers (N % 32 == 0 output channels, K a power of two in 32 ... 256, H % 16 == 0,
+ * W % 32 == 0, x smaller than 4 GB): input transform, the 36 contractions (fp32 MFMA) and the output transform in ONE persistent
+ * kernel -- V and M, 2.25x the input / output each, never leave the CU (through HBM they cost more than the 4x fewer FLOPs return at
+ * these sizes).  uf [36][K/8][2][N][4] = G W G^T in MFMA operand order, from the packed direct-form weights (w2e_conv_pack: any
+ * transpose / flip), once per pack.  Epilogues: act = 1 (noise_w*noise + bias, LeakyReLU 0.2, sqrt 2), act = 2 (+ bias[o],
+ * PReLU(slope[o]) if slope: w2e_conv3x3's), or dot_with / dot_out -- NOT accumulated: dot_out receives one partial per (channel,
+ * spatial block), [batch][N][H/16 * W/32] floats (written, no atomics: deterministic), which the caller sums over the last axis
+ * (w2e_channel_sums).  wgs > 0 caps the persistent grid (tests).  Rounding, max-norm relative to a float64 convolution at
+ * K = 128 ... 512: direct 3e-7, this form 1e-5 (its transforms multiply by up to 8 and 1/24) -- against the path's 1e-3 tolerance. */
 int w2e_wino_weights_fused(const float* wp, float* uf, int k_ch, int n_ch, void* stream);
 int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const float* out_scale, float* y, int batch, int k_ch,
                    int n_ch, int h, int w, int act, const float* noise, const float* noise_w, const float* bias, const float* slope,
-                   const float* dot_with, float* dot_out, int version, int wgs, void* stream);
+                   const float* dot_with, float* dot_out, int wgs, void* stream);
+
+/* ---- K1g  the F(4x4,3x3) form with the contraction on an OWN fp32-MFMA kernel and the output transform in its epilogue
+ * (model.py:270-274; models/facial_recognition/helpers.py:97-119) -- the wide same-resolution layers (N % 64 == 0, K % 8 == 0,
+ * H, W % 4 == 0).  Replaces the host-side composition w2e_wino_input -> vendor strided-batched GEMM -> w2e_wino_output:
+ *   w2e_wino_gemm_plan   for one layer call: tiles_padded (T = batch*H/4*W/4 rounded up to 32), the K split the library would use
+ *                        (1 = none; small layers split K so that 256 CUs have work) and the floats of `workspace` w2e_wino_gemm needs
+ *                        (fused-dot partials + split-K slabs; may be 0).  vf must hold 36 * K * tiles_padded floats.
+ *   w2e_wino_pack_input  x [B,K,H,W], in_scale [B,K] or NULL -> vf [36][K/8][2][tiles_padded][4]: B^T (in_scale * window) B in the
+ *                        order the MFMA consumes it: (xi, kc, h, t, c) = V[xi][k = 8*kc + 2*c + h][t], t = (b, tile row, tile column)
+ *   w2e_wino_gemm        y = epilogue(out_scale * A^T [sum_k U V] A) from uf (w2e_wino_weights_fused) and vf.  One workgroup = 64
+ *                        channels x 32 tiles x all 36 positions; operands global/L2 -> registers (no LDS in the K loop); M never
+ *                        reaches HBM.  Epilogues as w2e_wino_fused: act 1 (noise_w*noise + bias, LeakyReLU 0.2, sqrt 2), act 2
+ *                        (+ bias, PReLU(slope) if slope), or dot_with / dot_out: dot_out[b,o] += sum_p conv_unscaled * dot_with,
+ *                        WITHOUT atomics (per-segment partials in `workspace`, summed in a fixed order by a second launch; needs
+ *                        (H/4)*(W/4) tiles per plane a multiple of 32 or a power of two below it).  splits > 1: each K split writes
+ *                        its raw A^T M A into a slab of `workspace`, a second launch sums the slabs in order and applies the epilogue.
+ *                        No fp32 atomics on any path: results are bit-reproducible ("deterministic" hosts may use it).
+ * Rounding as the other F(4x4,3x3) forms: ~1e-5 max-norm relative to a float64 convolution at K = 128 ... 512. */
+int w2e_wino_gemm_plan(int batch, int k_ch, int n_ch, int h, int w, int* tiles_padded, int* splits, int64_t* workspace_floats);
+int w2e_wino_pack_input(const float* x, const float* in_scale, float* vf, int batch, int k_ch, int h, int w, int tiles_padded, void* stream);
+int w2e_wino_gemm(const float* uf, const float* vf, const float* out_scale, float* y, int batch, int k_ch, int n_ch, int h, int w,
+                  int tiles_padded, int splits, float* workspace, int act, const float* noise, const float* noise_w, const float* bias,
+                  const float* slope, const float* dot_with, float* dot_out, void* stream);
 
 /* Demodulation coefficients and their style gradient (model.py:241-243), [B,C]-sized:
  *   d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps),  wsq[o,i] = sum_k (scale*W[o,i,k])^2  [cout,cin]. */

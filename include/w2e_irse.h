@@ -24,9 +24,10 @@ extern "C" {
  *   stride-2 shortcut convolution, helpers.py:103-106);
  * mode W2E_CONV_UP (no epilogue): the adjoint of DOWN -- T[B,N,2h+1,2w+1] phase-planar, of which [1:,1:] is the input
  *   gradient of the padded stride-2 convolution.
- * in_scale / out_scale ([B,K] / [B,N]) / bias / slope ([N]) may be NULL (1 / 1 / 0 / identity).  h,w as in w2e_modconv3x3. */
+ * in_scale / out_scale ([B,K] / [B,N]) / bias / slope ([N]) may be NULL (1 / 1 / 0 / identity).  h,w and y_pitch as in
+ * w2e_modconv3x3 (y_pitch: the row pitch the caller allocated the phase-planar UP output with; checked; ignored otherwise). */
 int w2e_conv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y, int batch,
-                int k_ch, int n_ch, int h, int w, int down_pad, const float* bias, const float* slope, void* stream);
+                int k_ch, int n_ch, int h, int w, int y_pitch, int down_pad, const float* bias, const float* slope, void* stream);
 
 /* y = prelu(a[c]*x + b[c], slope[c]) over [B,C,HW]; a / b / slope may be NULL (1 / 0 / identity).
  * (eval-mode BatchNorm2d in front of a zero-padded convolution, helpers.py:111: the shift cannot be folded into
@@ -34,7 +35,8 @@ int w2e_conv3x3(int mode, const float* x, const float* wp, const float* in_scale
 int w2e_affine_act_fwd(const float* x, const float* a, const float* b, const float* slope, float* y, int batch, int channels,
                        int64_t hw, void* stream);
 /* gx = a[c] * gy * (y > 0 ? 1 : slope[c])   (y = the forward OUTPUT; valid for slope > 0, where sign(y) = sign(pre)).
- * planar != 0: gy is the phase-planar T of W2E_CONV_UP ([B,C,2,2,h/2+1,WP]) and the element read for (yy,xx) is
+ * planar != 0: gy is the phase-planar T of W2E_CONV_UP ([B,C,2,2,h/2+1,WP]), `planar` = the row pitch WP the caller allocated it
+ * with (must equal W2E_PLANAR_PITCH(width/2): a mismatch is refused instead of read past), and the element read for (yy,xx) is
  * T[yy+1][xx+1] -- the crop that turns the adjoint of DOWN into the gradient of the padded stride-2 convolution;
  * then height x width (even) describe gx and hw = height*width. */
 int w2e_affine_act_bwd(const float* gy, const float* y, const float* a, const float* slope, float* gx, int batch, int channels,
@@ -62,7 +64,8 @@ int w2e_se_apply_fwd(const float* t, const float* gate, const float* shortcut, i
 int w2e_se_apply_bwd(const float* gout, const float* gate, const float* gpool, float* g_t, int batch, int channels, int64_t hw,
                      void* stream);
 /* gx[b,c,s*y,s*x] += g[b,c,y,x]  (adjoint of the strided shortcut; s = 1: a plain in-place add).
- * planar != 0: g is a phase-planar UP output T and gx[b,c,y,x] += T[y+1][x+1] over the whole [H*s... see w2e_affine_act_bwd]. */
+ * planar != 0: g is a phase-planar UP output T (`planar` = its row pitch, checked as in w2e_affine_act_bwd) and
+ * gx[b,c,y,x] += T[y+1][x+1]. */
 int w2e_shortcut_add_bwd(float* gx, const float* g, int batch, int channels, int height, int width, int stride, int planar,
                          void* stream);
 

@@ -40,8 +40,18 @@ def test_ctypes_prototypes_cover_the_header():
     assert sorted(list(_lib._PROTOS) + list(_lib_vit.PROTOS) + list(run_attention.PROTOS) + list(irse_hip.PROTOS)) == _declared_symbols()
 
 
+def test_driver_build_hook_checks_hold_for_the_built_library(lib):
+    """__graft_entry__.build()'s post-build checks (it asserted ABI version 1 two rounds after the ABI moved on: the
+    compile passed and the hook raised).  The version now comes from include/w2e.h everywhere."""
+    import __graft_entry__ as G
+    from where2edit_amd import _lib
+    G.check_built_library(lib)
+    assert lib.w2e_version() == _lib.header_version() >= 3
+
+
 def test_version_and_argument_errors_do_not_need_a_gpu(lib):
-    assert lib.w2e_version() == 3
+    from where2edit_amd import _lib
+    assert lib.w2e_version() == _lib.header_version()
     # options: read from the environment once at load, then only through the ABI; unknown names are refused
     assert lib.w2e_set_option(b"deterministic", b"1") == 0
     v = ctypes.c_int(-1)
@@ -54,6 +64,74 @@ def test_version_and_argument_errors_do_not_need_a_gpu(lib):
     rc = lib.w2e_clip_preproc_fwd(None, None, ctypes.c_int64(1), 1024, None)
     assert rc != 0 and b"null" in lib.w2e_last_error()
     lib.w2e_upfirdn2d.argtypes = None
+
+
+def test_a_caller_with_another_planar_pitch_is_refused_not_read_past(lib):
+    """Round 3's e7 memory fault: the CALLER allocates the phase-planar transposed-conv output, the kernels index it with
+    W2E_PLANAR_PITCH; a caller still on ABI 2's pitch (W+1 rounded to 4 floats) handed over a buffer ~15 % too small.  Every entry point
+    that takes a planar tensor now takes the pitch the caller allocated with and refuses anything but its own -- before any HIP call,
+    so this needs no GPU (the pointers are never dereferenced)."""
+    P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    lib.w2e_last_error.restype = ctypes.c_char_p
+    w = 512
+    mine, old = ((w + 1) + 15) & ~15, ((w + 1) + 3) & ~3
+    assert mine == 528 and old == 516
+    d = P(4096)  # a non-null, aligned dummy address
+    lib.w2e_modconv3x3.argtypes = [I, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, P]
+    rc = lib.w2e_modconv3x3(1, d, d, None, None, d, 1, 64, 32, w, w, old, 0, None, None, None, None, None, None)
+    assert rc != 0 and b"row pitch of 516" in lib.w2e_last_error() and b"528" in lib.w2e_last_error()
+    lib.w2e_upfirdn2d.argtypes = [P, P, P, L] + [I] * 14 + [P] * 4 + [I, F, F, P]
+    rc = lib.w2e_upfirdn2d(d, d, d, 32, 2 * w + 1, 2 * w + 1, 2 * w, 2 * w, 4, 4, 1, 1, 1, 1, 1, 1, old, 0, None, None, None, None, 1, 0.2, 1.0, None)
+    assert rc != 0 and b"row pitch of 516" in lib.w2e_last_error()
+    lib.w2e_conv3x3.argtypes = [I, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]
+    rc = lib.w2e_conv3x3(1, d, d, None, None, d, 1, 64, 64, 56, 56, ((56 + 1) + 3) & ~3, 0, None, None, None)
+    assert rc != 0 and b"row pitch of 60" in lib.w2e_last_error() and b"64" in lib.w2e_last_error()
+    lib.w2e_affine_act_bwd.argtypes = [P, P, P, P, P, I, I, I, I, I, P]
+    rc = lib.w2e_affine_act_bwd(d, d, None, None, d, 1, 64, 112, 112, 60, None)
+    assert rc != 0 and b"row pitch of 60" in lib.w2e_last_error()
+    lib.w2e_shortcut_add_bwd.argtypes = [P, P, I, I, I, I, I, I, P]
+    rc = lib.w2e_shortcut_add_bwd(d, d, 1, 64, 112, 112, 1, 60, None)
+    assert rc != 0 and b"row pitch of 60" in lib.w2e_last_error()
+    for fn in (lib.w2e_modconv3x3, lib.w2e_upfirdn2d, lib.w2e_conv3x3, lib.w2e_affine_act_bwd, lib.w2e_shortcut_add_bwd):
+        fn.argtypes = None
+
+
+def test_winograd_selection_is_host_logic_and_respects_the_4gb_descriptor(lib, monkeypatch):
+    """the fused kernel addresses x through ONE buffer descriptor (< 4 GB).  At total batch 32 the 32 @ 1024^2
+    layer is exactly 4 GiB: the selection must fall back (here: to the direct kernel) instead of handing w2e_wino_fused a tensor it
+    refuses; likewise 64 @ 512^2 at 64 and 128 @ 256^2 at 128 (there the GEMM form takes over).  No GPU: shapes only."""
+    from where2edit_amd import _lib, functional as K
+    monkeypatch.setattr(_lib, "get_option", lambda name: {"conv_precision": 0, "deterministic": 0, "tune_cfg": -1}[name])
+    monkeypatch.setattr(K, "WINOGRAD", "auto")
+
+    class X:  # _wino_form only reads the batch
+        def __init__(self, b):
+            self.shape = (b,)
+    assert K._wino_form(X(8), 32, 32, 1024, 1024, None) == K.FUSED
+    assert K._wino_form(X(31), 32, 32, 1024, 1024, None) == K.FUSED
+    assert K._wino_form(X(32), 32, 32, 1024, 1024, None) == 0          # 4 GiB: past the descriptor -> direct kernel
+    assert K._wino_form(X(64), 64, 64, 512, 512, None) == 0
+    assert K._wino_form(X(127), 128, 128, 256, 256, None) == K.FUSED
+    assert K._wino_form(X(128), 128, 128, 256, 256, None) == 0          # (the GEMM form's V would be 9.7 GB here: past ITS descriptor too)
+    assert K._wino_form(X(8), 512, 512, 64, 64, None) == 4 and K._wino_form(X(8), 256, 256, 128, 128, X(8)) == 4
+    assert K._wino_form(X(8), 512, 512, 8, 8, None) == 0 and K._wino_form(X(8), 512, 256, 64, 64, None) == 4
+    assert not K._gemm_shape_ok(8, 512, 48, 64, 64) and not K._gemm_shape_ok(8, 20, 64, 64, 64) and not K._gemm_shape_ok(8, 64, 64, 30, 32)
+    assert K._gemm_shape_ok(16, 128, 256, 28, 28, dot=False) and not K._gemm_shape_ok(16, 128, 256, 28, 28, dot=True)  # 49 tiles: no fused dot
+    # the plan entry point is host code too: padded tiles, K split for the layers that would leave CUs idle, workspace size
+    tp, sp, ws = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    lib.w2e_wino_gemm_plan.argtypes = None
+    assert lib.w2e_wino_gemm_plan(8, 512, 512, 64, 64, ctypes.byref(tp), ctypes.byref(sp), ctypes.byref(ws)) == 0
+    assert (tp.value, sp.value, ws.value) == (2048, 1, 8 * 512 * 8)
+    assert lib.w2e_wino_gemm_plan(3, 64, 64, 28, 28, ctypes.byref(tp), ctypes.byref(sp), ctypes.byref(ws)) == 0
+    assert tp.value == 160 and sp.value >= 1 and ws.value == 3 * 64 * 1 + (sp.value * 3 * 64 * 28 * 28 if sp.value > 1 else 0)
+    assert lib.w2e_wino_gemm_plan(8, 512, 48, 64, 64, ctypes.byref(tp), ctypes.byref(sp), ctypes.byref(ws)) != 0  # N % 64
+    with pytest.raises(ValueError):
+        K._parse_winograd("off")  # (ADVICE r3: an unknown value used to mean "auto")
+    with pytest.raises(ValueError):
+        K._parse_winograd("f2")   # (the F(2x2,3x3) form went with the vendor GEMM)
+    assert K._parse_winograd("") == "auto" and K._parse_winograd("0") is False and K._parse_winograd("4") == 4
+    with pytest.raises(ValueError):
+        K.set_winograd(2)
 
 
 def test_generator_state_dict_schema_matches_rosinality_checkpoints():

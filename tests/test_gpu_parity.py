@@ -862,7 +862,8 @@ def test_modconv_ragged_channels_never_write_past_the_output(mode, w2e_opt):
     tail = 1 << 16
     buf = torch.full((numel + tail,), 1234.5, device=DEV)
     dot = torch.zeros(b, n, device=DEV) if dot_with is not None else None
-    call("w2e_modconv3x3", kmode, ptr(x), ptr(pack), ptr(s_in), ptr(s_out), ptr(buf), b, k, n, h, w, int(act is not None),
+    call("w2e_modconv3x3", kmode, ptr(x), ptr(pack), ptr(s_in), ptr(s_out), ptr(buf), b, k, n, h, w,
+         K.planar_pitch(w) if mode == "up" else 0, int(act is not None),
          ptr(noise) if act else None, ptr(nw) if act else None, ptr(bias) if act else None, ptr(dot_with), ptr(dot), stream_ptr())
     torch.cuda.synchronize()
     assert torch.all(buf[numel:] == 1234.5), f"{mode}: wrote past the end of the output"
@@ -999,22 +1000,21 @@ def test_modconv_pipelined_kernel(b, k, n, h, w, wgs, w2e_opt):
     assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "same, unmodulated")
 
 
-@pytest.mark.parametrize("m,b,k,n,h,w", [(2, 2, 64, 48, 16, 16), (2, 1, 24, 40, 32, 16), (2, 3, 512, 512, 16, 16), (2, 2, 16, 16, 64, 32),
-                                         (4, 3, 64, 48, 16, 16), (4, 1, 24, 40, 32, 32), (4, 2, 512, 512, 32, 32), (4, 5, 16, 16, 64, 32),
-                                         (4, 2, 128, 128, 16, 32),
+@pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 64, 16, 16), (4, 1, 64, 128, 32, 32), (4, 2, 512, 512, 32, 32), (4, 5, 128, 64, 64, 32),
+                                         (4, 2, 128, 128, 16, 32), (4, 1, 192, 64, 8, 16),
+                                         (11, 2, 512, 512, 16, 16), (11, 3, 64, 64, 16, 16), (11, 1, 128, 64, 32, 64), (12, 2, 256, 128, 32, 32),
                                          (8, 2, 32, 32, 32, 64), (8, 1, 64, 64, 16, 32), (8, 3, 128, 32, 48, 32), (8, 2, 64, 32, 32, 32), (8, 5, 32, 64, 64, 64),
-                                         (8, 2, 32, 128, 32, 32), (9, 3, 40, 32, 48, 32), (9, 2, 32, 64, 32, 64),
-                                         (10, 2, 32, 32, 32, 64), (10, 1, 64, 64, 16, 32), (10, 3, 128, 32, 48, 32), (10, 5, 32, 64, 64, 64),
-                                         (10, 2, 32, 128, 32, 32), (10, 1, 32, 32, 64, 96)])
+                                         (8, 2, 32, 128, 32, 32), (8, 1, 32, 32, 64, 96)])
 def test_modconv_winograd_form(m, b, k, n, h, w):
-    """K1w: the Winograd forms F(2x2,3x3) and F(4x4,3x3) of the same-resolution conv (w2e_wino_weights / _input / _output around one
-    strided-batched fp32 GEMM) against float64 convolutions, every epilogue of w2e_modconv3x3 -- plain, unmodulated, noise + bias +
-    LeakyReLU, and the input-gradient pass (transposed + flipped pack) with the fused per-channel dot (16 tiles per plane: the
-    segmented reduction; 64 and more: whole waves) -- and against the direct kernel; m = 8: the FUSED F(4x4,3x3) kernel
-    (w2e_wino_fused version 2 -- persistent, loader + matrix waves, a grid of 3 workgroups so that each walks through several
-    blocks, 1 to 4 output-channel blocks, K = 32 ... 128, the fused dot as per-block partials -- and, m = 9, version 1: one workgroup
-    per block, K not a power of two, atomics), image borders on every side.  Tolerances: FWD_TOL = 1e-4 against float64
-    for both; the measured distance is printed by -s (F(2x2): ~6e-7, F(4x4): ~1e-5 at K = 512)."""
+    """K1w / K1g: the Winograd F(4x4,3x3) forms of the same-resolution conv against float64 convolutions, every epilogue of w2e_modconv3x3
+    -- plain, unmodulated, noise + bias + LeakyReLU, and the input-gradient pass (transposed + flipped pack) with the fused per-channel
+    dot -- and against the direct kernel.  m = 4: the GEMM form on the OWN contraction kernel (w2e_wino_pack_input + w2e_wino_gemm:
+    output transform in its epilogue; 8 / 16 / 32 / 64 / 128 tiles per plane: the segmented dot reduction and whole 32-tile segments;
+    tile counts that pad to 32; K = 64 ... 512 incl. a non-power-of-two chunk count), m = 11 / 12: the same with K split 3 / 2 ways
+    (slabs + w2e's finish kernel), all of them run twice and compared BIT FOR BIT (no atomics on any of its paths); m = 8: the FUSED
+    kernel (w2e_wino_fused: persistent, transform + matrix waves, the patch by LDS-DMA; a grid of 3 workgroups so that each walks
+    through several blocks, 1 to 4 output-channel blocks, K = 32 ... 128, both block shapes, the fused dot as per-block partials),
+    image borders on every side.  Tolerances: FWD_TOL = 1e-4 against float64; the measured distance is printed by -s (~1e-5 at K = 512)."""
     import torch.nn.functional as F
     from where2edit_amd import functional as K
     g = torch.Generator().manual_seed(17 * k + n + h)
@@ -1033,10 +1033,12 @@ def test_modconv_winograd_form(m, b, k, n, h, w):
     gy = torch.randn(b, n, h, w, generator=g).to(DEV)          # the input-gradient pass: in_scale = s_out (demod), out_scale = s_in
     xdot = torch.randn(b, k, h, w, generator=g).to(DEV)
     graw = F.conv_transpose2d(gy.double() * so, wd, padding=1)
-    saved, saved_f = K.WINOGRAD, (K.FUSED_VERSION, K.FUSED_WGS)
-    if m >= 8:  # 8: version 2, 9: version 1, 10: version 3 (the patch by LDS-DMA); 3 workgroups: several blocks each
-        K.FUSED_VERSION, K.FUSED_WGS = {8: (2, 3), 9: (1, 0), 10: (3, 3)}[m]
-        m = 8
+    saved, saved_f, saved_s = K.WINOGRAD, K.FUSED_WGS, K.GEMM_SPLITS
+    if m in (11, 12):  # the GEMM form with a forced K split
+        K.GEMM_SPLITS = {11: 3, 12: 2}[m]
+        m = 4
+    elif m == 8:  # 3 workgroups: several blocks each
+        K.FUSED_WGS = 3
     try:
         K.set_winograd(False)
         y_direct, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
@@ -1049,17 +1051,28 @@ def test_modconv_winograd_form(m, b, k, n, h, w):
         assert_close(y, F.conv2d(x.double(), wd, padding=1), FWD_TOL, "winograd, unmodulated")
         y, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
         assert_close(y, F.leaky_relu(pre, 0.2) * 2 ** 0.5, FWD_TOL, "winograd + act")
-        assert_close(y, y_direct, 5e-6 if m == 2 else 1e-4, "winograd == direct kernel")
+        assert_close(y, y_direct, 1e-4, "winograd == direct kernel")
         print(f"F({m}x{m},3x3) K={k}: |y - direct| / |direct| = {rel_err(y, y_direct):.2e}")
+        K.WINO_LOG = []
         gx, gs = K._modconv_raw(K.MODE_SAME, gy, bwd, s_out, s_in, h, w, dot_with=xdot)
+        log, K.WINO_LOG = K.WINO_LOG, None
+        if K._wino_form(gy, n, k, h, w, xdot):  # (the form under test ran the gradient pass too -- unless its shapes exclude the transposed layer)
+            assert len(log) == 1 and ("gemm" in log[0]) == (m == 4) and "dot" in log[0], log
+        else:
+            assert m == 8 and not log, log
         assert_close(gx, graw * s_in.double()[:, :, None, None], FWD_TOL, "winograd input gradient")
         assert_close(gs, (graw * xdot.double()).sum((2, 3)), FWD_TOL, "winograd fused dot")
-        assert_close(gx, gx_direct, 5e-6 if m == 2 else 1e-4, "input gradient: winograd == direct")
-        assert_close(gs, gs_direct, 1e-5 if m == 2 else 1e-4, "fused dot: winograd == direct")
+        assert_close(gx, gx_direct, 1e-4, "input gradient: winograd == direct")
+        assert_close(gs, gs_direct, 1e-4, "fused dot: winograd == direct")
+        if m == 4:  # fixed summation order everywhere (K chunks ascending, slabs ascending, dot segments ascending): bit-identical reruns
+            y2, _ = K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, act=(noise, nw, bias))
+            gx2, gs2 = K._modconv_raw(K.MODE_SAME, gy, bwd, s_out, s_in, h, w, dot_with=xdot)
+            assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(gs, gs2), "the GEMM form is not bit-reproducible"
         out = torch.full((b + 1, n, h, w), 7.0, device=DEV)      # writing into the tail rows of a larger batch
         K._modconv_raw(K.MODE_SAME, x, fwd, s_in, s_out, h, w, out=out[1:])
         assert_close(out[1:], ref, FWD_TOL, "winograd into a view")
         assert float(out[0].min()) == 7.0 and float(out[0].max()) == 7.0
     finally:
         K.set_winograd(saved)
-        K.FUSED_VERSION, K.FUSED_WGS = saved_f
+        K.FUSED_WGS = saved_f
+        K.GEMM_SPLITS, K.WINO_LOG = saved_s, None

@@ -29,11 +29,10 @@ for B, Ci, C, H in shapes:
     run = lambda form: I.conv3x3(x, wp, C, H, H, bias=bias, slope=slope, form=form)
     base = timeit(lambda: run(0))
     res.append(f"direct {base:6.1f}us ({flop / base / 1e6:5.1f} TF/s)")
-    for m in (2, 4):
-        if H % m == 0:
-            t = timeit(lambda: run(m))
-            res.append(f"F({m}x{m}) {t:6.1f}us ({flop / t / 1e6:5.1f})")
-    if K._fused_shape_ok(B, Ci, C, H, H) and K._fused_version(Ci, C, False) == 3:
+    if K._gemm_shape_ok(B, Ci, C, H, H, dot=False):
+        t = timeit(lambda: run(4))
+        res.append(f"F(4x4) gemm {t:6.1f}us ({flop / t / 1e6:5.1f})")
+    if K._fused_shape_ok(B, Ci, C, H, H):
         t = timeit(lambda: run(K.FUSED))
         res.append(f"fused {t:6.1f}us ({flop / t / 1e6:5.1f})")
     res.append(f"chosen: {({0: 'direct', K.FUSED: 'fused'}).get(I._wino_form(B, Ci, C, H, H), I._wino_form(B, Ci, C, H, H))}")

@@ -22,7 +22,7 @@ _PROTOS = {
     "w2e_last_error": (ctypes.c_char_p, []),
     "w2e_set_option": (_I, [ctypes.c_char_p, ctypes.c_char_p]),
     "w2e_get_option": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
-    "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
+    "w2e_upfirdn2d": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _F, _P]),
     "w2e_blur_adjoint_actbwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _F, _P]),
     "w2e_mapper_pixelnorm": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "w2e_mapper_linear": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P]),
@@ -37,12 +37,12 @@ _PROTOS = {
     "w2e_bias_act_bwd": (_I, [_P, _P, _P, _L, _F, _F, _P]),
     "w2e_bias_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _F, _F, _P]),
     "w2e_conv_pack": (_I, [_P, _P, _I, _I, _F, _I, _I, _P]),
-    "w2e_modconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "w2e_wino_weights": (_I, [_P, _P, _I, _I, _I, _P]),
-    "w2e_wino_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "w2e_modconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "w2e_wino_weights_fused": (_I, [_P, _P, _I, _I, _P]),
-    "w2e_wino_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "w2e_wino_output": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "w2e_wino_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "w2e_wino_gemm_plan": (_I, [_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
+    "w2e_wino_pack_input": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "w2e_wino_gemm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "w2e_demod_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "w2e_demod_all_fwd": (_I, [ctypes.POINTER(DemodLayer), _I, _I, _F, _P]),
     "w2e_demod_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -63,6 +63,17 @@ _PROTOS = {
 }
 
 _lib = None
+
+
+def header_version():
+    """W2E_VERSION as include/w2e.h states it: the one place the ABI version is written down (the loader, the driver's
+    build hook and the tests all compare the built library against THIS, so none of them can go stale on its own)."""
+    import re
+    h = os.path.join(os.path.dirname(_build.PKG), "include", "w2e.h")
+    m = re.search(r"^#define\s+W2E_VERSION\s+(\d+)", open(h).read(), re.M)
+    if not m:
+        raise RuntimeError(f"{h}: no W2E_VERSION")
+    return int(m.group(1))
 
 
 def lib_path():
@@ -87,8 +98,8 @@ def load():
         _ra.declare(lib)
         from . import irse_hip as _ir  # the IR-SE50 entry points (include/w2e_irse.h)
         _ir.declare(lib)
-        if lib.w2e_version() != 3:
-            raise RuntimeError("libw2e.so version mismatch: rebuild with `python -m where2edit_amd.build --force`")
+        if lib.w2e_version() != header_version():
+            raise RuntimeError(f"libw2e.so is ABI {lib.w2e_version()}, include/w2e.h says {header_version()}: rebuild with `python -m where2edit_amd.build --force`")
         _lib = lib
     return _lib
 

@@ -33,6 +33,10 @@ static inline bool big_lds_once(const void* fn, unsigned* done_mask) {
     return true;
 }
 
+// Compute units of the CURRENT device (cached per device index; 256 when the query fails): the persistent kernels size their
+// grids from it.  (Round 3 kept one `static int` per call site: the count of whichever device came first, for every device.)
+int cu_count();
+
 // Argument check: records the message and makes the entry point return 1.
 #define W2E_REQUIRE(cond, ...)        \
     do {                              \

@@ -245,10 +245,14 @@ int w2e_affine_act_bwd(const float* gy, const float* y, const float* a, const fl
     W2E_REQUIRE(gy && gx, "affine_act_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && channels > 0 && height > 0 && width > 0, "affine_act_bwd: bad dims");
     W2E_REQUIRE(!planar || ((height & 1) == 0 && (width & 1) == 0), "affine_act_bwd: the planar crop needs even sizes");
+    // planar: 0 = gy is dense [B,C,H,W]; otherwise the ROW PITCH of the phase-planar gy the caller allocated -- it must be this library's
+    W2E_REQUIRE(!planar || planar == W2E_PLANAR_PITCH(width / 2),
+                "affine_act_bwd: planar gradient with a row pitch of %d floats, this library's layout has %d (W2E_PLANAR_PITCH, ABI %d): rebuild the caller",
+                planar, W2E_PLANAR_PITCH(width / 2), W2E_VERSION);
     const int64_t total = (int64_t)batch * channels * height * width;
     if (total == 0) return 0;
     affine_act_bwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gy, y, a, slope, gx, channels, height, width,
-                                                                                    planar, total);
+                                                                                    planar != 0, total);
     W2E_LAUNCH_CHECK("affine_act_bwd");
     return 0;
 }
@@ -315,9 +319,12 @@ int w2e_shortcut_add_bwd(float* gx, const float* g, int batch, int channels, int
     W2E_REQUIRE(gx && g, "shortcut_add_bwd: null tensor");
     W2E_REQUIRE(batch >= 0 && channels > 0 && height > 0 && width > 0 && stride >= 1, "shortcut_add_bwd: bad dims");
     W2E_REQUIRE(!planar || (stride == 1 && (height & 1) == 0 && (width & 1) == 0), "shortcut_add_bwd: planar form is stride 1, even sizes");
+    W2E_REQUIRE(!planar || planar == W2E_PLANAR_PITCH(width / 2),
+                "shortcut_add_bwd: planar gradient with a row pitch of %d floats, this library's layout has %d (W2E_PLANAR_PITCH, ABI %d): rebuild the caller",
+                planar, W2E_PLANAR_PITCH(width / 2), W2E_VERSION);
     const int64_t total = (int64_t)batch * channels * height * width;
     if (total == 0) return 0;
-    shortcut_add_bwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gx, g, height, width, stride, planar, total);
+    shortcut_add_bwd_kernel<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gx, g, height, width, stride, planar != 0, total);
     W2E_LAUNCH_CHECK("shortcut_add_bwd");
     return 0;
 }

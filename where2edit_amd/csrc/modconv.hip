@@ -1646,10 +1646,13 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     if (up) {
         // border units (one wave each): image x 32-channel block x 32-position block of the last row (W+1 positions) / column (H)
         p.groups_row = (int)ceil_div(w + 1, 32), p.groups_col = (int)ceil_div(h, 32);
-        p.border_wgs = (int)((int64_t)batch * (p.groups_row + p.groups_col) * ceil_div(n_ch, 32));  // one workgroup per unit
+        const int64_t border = (int64_t)batch * (p.groups_row + p.groups_col) * ceil_div(n_ch, 32);  // one workgroup per unit
+        W2E_REQUIRE(border < ((int64_t)1 << 31), "modconv3x3: %lld border units are too many", (long long)border);
+        p.border_wgs = (int)border;
         if (lds < (size_t)(nt_best / 64) * 32 * 64 * sizeof(float)) lds = (size_t)(nt_best / 64) * 32 * 64 * sizeof(float);  // their join buffer
     }
     const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
+    W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid of %lld workgroups is too large", (long long)grid);  // (cast to int at every launch below)
 #ifdef W2E_TUNING
     // tuning aid: W2E_TUNE_CLOCK=1 stamps every workgroup and reports the in-kernel shader clock (s_memtime ticks per
     // 100 MHz s_memrealtime tick) of every 64th launch -- the DVFS-limited clock is what an MFMA-bound kernel is priced by
@@ -1698,30 +1701,25 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
             const size_t lds_p = sizeof(float) * (2 * ((size_t)72 * tn + 8 * (size_t)q.plane) + 2 * ((size_t)k8 + 2 * tn));
             if (nt64 * dmax < ((int64_t)1 << 32) && lds_p <= 160 * 1024 && (nt64 >= 512 || opt.tune_pipe == 1)) {
                 q.n_tiles = (int)nt64;
-                static int cus = 0;
-                if (!cus) {
-                    int dev = 0;
-                    hipDeviceProp_t prop;
-                    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-                }
+                const int cus = cu_count();
                 int wgs = q.n_tiles < cus ? q.n_tiles : cus;
                 if (opt.tune_pipe_wgs > 0 && opt.tune_pipe_wgs < wgs) wgs = opt.tune_pipe_wgs;  // (tests: several tiles per workgroup on small inputs)
                 if (opt.tune_print) fprintf(stderr, "  pipelined kernel: %d tiles of %dx%d px x %d ch on %d workgroups, %zu B LDS\n", q.n_tiles, th, tw, tn, wgs, lds_p);
                 static unsigned done_mask[4] = {0, 0, 0, 0};
                 if (n32) {
                     if (act) {
-                        big_lds_once((const void*)modconv_pipe_kernel<EPI_ACT, 1, 4, 1, 8>, &done_mask[0]);
+                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_ACT, 1, 4, 1, 8>, &done_mask[0]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
                         modconv_pipe_kernel<EPI_ACT, 1, 4, 1, 8><<<wgs, 512, lds_p, s>>>(q);
                     } else {
-                        big_lds_once((const void*)modconv_pipe_kernel<EPI_PLAIN, 1, 4, 1, 8>, &done_mask[1]);
+                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_PLAIN, 1, 4, 1, 8>, &done_mask[1]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
                         modconv_pipe_kernel<EPI_PLAIN, 1, 4, 1, 8><<<wgs, 512, lds_p, s>>>(q);
                     }
                 } else {
                     if (act) {
-                        big_lds_once((const void*)modconv_pipe_kernel<EPI_ACT, 2, 2, 1, 8>, &done_mask[2]);
+                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_ACT, 2, 2, 1, 8>, &done_mask[2]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
                         modconv_pipe_kernel<EPI_ACT, 2, 2, 1, 8><<<wgs, 512, lds_p, s>>>(q);
                     } else {
-                        big_lds_once((const void*)modconv_pipe_kernel<EPI_PLAIN, 2, 2, 1, 8>, &done_mask[3]);
+                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_PLAIN, 2, 2, 1, 8>, &done_mask[3]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
                         modconv_pipe_kernel<EPI_PLAIN, 2, 2, 1, 8><<<wgs, 512, lds_p, s>>>(q);
                     }
                 }
@@ -1805,17 +1803,26 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     return 0;
 }
 
+// The caller allocates the phase-planar output of UP: its row pitch must be THIS library's (round 3's e7 memory fault: a caller built
+// against ABI 2's pitch handed a buffer 15 % too small to kernels that index with W2E_PLANAR_PITCH).
+#define W2E_CHECK_UP_PITCH(name)                                                                                                       \
+    W2E_REQUIRE(mode != W2E_CONV_UP || y_pitch == W2E_PLANAR_PITCH(w),                                                                 \
+                name ": UP output with a row pitch of %d floats, this library's layout has %d (W2E_PLANAR_PITCH, ABI %d): rebuild the caller", \
+                y_pitch, W2E_PLANAR_PITCH(w), W2E_VERSION)
+
 extern "C" int w2e_modconv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale,
-                              float* y, int batch, int k_ch, int n_ch, int h, int w, int act, const float* noise,
+                              float* y, int batch, int k_ch, int n_ch, int h, int w, int y_pitch, int act, const float* noise,
                               const float* noise_w, const float* bias, const float* dot_with, float* dot_out,
                               void* stream) {
+    W2E_CHECK_UP_PITCH("modconv3x3");
     return conv_impl(mode, x, wp, in_scale, out_scale, y, batch, k_ch, n_ch, h, w, act, noise, noise_w, bias, dot_with, dot_out,
                      nullptr, 0, 0, stream);
 }
 
 extern "C" int w2e_conv3x3(int mode, const float* x, const float* wp, const float* in_scale, const float* out_scale, float* y,
-                           int batch, int k_ch, int n_ch, int h, int w, int down_pad, const float* bias, const float* slope,
+                           int batch, int k_ch, int n_ch, int h, int w, int y_pitch, int down_pad, const float* bias, const float* slope,
                            void* stream) {
+    W2E_CHECK_UP_PITCH("conv3x3");
     const int prelu = (bias || slope) ? 1 : 0;
     W2E_REQUIRE(!(prelu && mode == W2E_CONV_UP), "conv3x3: no bias / PReLU epilogue in UP mode");
     return conv_impl(mode, x, wp, in_scale, out_scale, y, batch, k_ch, n_ch, h, w, 0, nullptr, nullptr, bias, nullptr, nullptr,

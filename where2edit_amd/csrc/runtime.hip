@@ -66,6 +66,17 @@ static OptionsInit g_opt_init;  // runs when the shared library is loaded
 
 const Options& options() { return g_opt; }
 
+int cu_count() {
+    static int cached[32];  // 0 = not asked yet; a racing first call stores the same value twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+    if (!cached[dev]) {
+        hipDeviceProp_t prop;
+        cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cached[dev];
+}
+
 __global__ void zero_kernel(unsigned* __restrict__ p, size_t words) {
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += step) p[i] = 0u;

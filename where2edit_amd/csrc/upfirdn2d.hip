@@ -769,8 +769,8 @@ __global__ void upfirdn_generic_kernel(UpfirdnParams p, int64_t total) {
 using namespace w2e;
 
 extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_t planes, int in_h, int in_w, int out_h,
-                             int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout, int act,
-                             const float* out_scale, const float* noise, const float* noise_w, const float* bias,
+                             int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0, int flip, int in_layout, int in_pitch,
+                             int act, const float* out_scale, const float* noise, const float* noise_w, const float* bias,
                              int channels, float slope, float gain, void* stream) {
     W2E_REQUIRE(x && kern && y, "upfirdn2d: null tensor");
     W2E_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && out_h >= 0 && out_w >= 0, "upfirdn2d: bad sizes");
@@ -783,6 +783,11 @@ extern "C" int w2e_upfirdn2d(const float* x, const float* kern, float* y, int64_
     if (total == 0) return 0;
     W2E_REQUIRE(in_layout == 0 || (in_layout == 1 && up == 1 && down == 1 && kh == 4 && kw == 4 && out_w >= 32),
                 "upfirdn2d: the phase-planar input layout is implemented for the 4x4, up=down=1 tile kernel only");
+    // The caller allocated the planar image: its row pitch must be THIS library's (the kernels index with W2E_PLANAR_PITCH; a caller built
+    // against another pitch hands over a buffer of another size and the kernel would read past it -- round 3's e7 memory fault).
+    W2E_REQUIRE(in_layout == 0 || in_pitch == W2E_PLANAR_PITCH((in_w - 1) >> 1),
+                "upfirdn2d: planar input with a row pitch of %d floats, this library's layout has %d (W2E_PLANAR_PITCH, ABI %d): rebuild the caller",
+                in_pitch, W2E_PLANAR_PITCH((in_w - 1) >> 1), W2E_VERSION);
     const int tune = options().tune_blur;
     UpfirdnParams p{x, kern, y, planes, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, flip, tune, in_layout,
                     act, out_scale, noise, noise_w, bias, channels > 0 ? channels : 1, slope, gain, nullptr, nullptr};

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns the device memory (outputs are torch.empty on 
 the stream (kernels are enqueued on torch's current HIP stream) and the autograd tape.  All arithmetic
 on image-sized tensors happens in the HIP kernels; torch ops are used only on [B,C]-sized style math.
 """
+import ctypes
 import math
 import os
 
@@ -151,7 +152,7 @@ def _upfirdn2d_raw(x, kernel, out_h, out_w, up, down, pad_x0, pad_y0, flip, act=
         a = (1, ptr(out_scale), ptr(noise), ptr(noise_w), ptr(bias), c, 0.2, SQRT2)
     sp = profiling.span("upfirdn2d", 4.0 * n * c * (h * w + out_h * out_w))  # algorithmic bytes: read x + write y
     call("w2e_upfirdn2d", ptr(x), ptr(kernel), ptr(y), n * c, h, w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0,
-         int(flip), int(planar_hw is not None), *a, stream_ptr())
+         int(flip), int(planar_hw is not None), x.shape[-1] if planar_hw is not None else 0, *a, stream_ptr())
     if sp is not None:
         sp.end()
     return y
@@ -244,16 +245,22 @@ def conv_pack(weight, scale, transpose, flip):
 
 MODE_SAME, MODE_UP, MODE_DOWN = 0, 1, 2
 
-# ---- Winograd forms of the same-resolution layers (include/w2e.h, K1w): input transform -> ONE strided-batched fp32 GEMM
-# (P x [N,K] x [K,tiles], the vendor library through torch.bmm; P = 16 for F(2x2,3x3), 36 for F(4x4,3x3)) -> output transform with the
-# direct kernel's epilogues.  WINOGRAD (W2E_WINOGRAD, read once here):
-#   "auto"  per layer, what measures fastest (profiles/r03_winograd.txt): F(4x4,3x3) for K, N >= 128 at 16^2 ... 256^2 -- its
-#           transform-domain tensors are 2.25x the input / output and its GEMMs a quarter of the direct FLOPs; batch 8: 512 -> 512 @ 64^2
-#           1.05 -> 0.39 ms, 256 -> 256 @ 128^2 1.07 -> 0.48; the FUSED kernel (w2e_wino_fused: nothing transform-domain in HBM) for
-#           128 @ 256^2 (1.10 -> 0.62), 64 @ 512^2 (1.16 -> 0.72) and 32 @ 1024^2 (1.29 -> 0.98).  Rounding ~1e-5 relative (direct: 3e-7)
-#   "f2"    F(2x2,3x3) wherever it beats the direct kernel (K, N >= 256 at 16^2 ... 128^2): rounding 6e-7, about half of "auto"'s gain
-#   False   direct kernels only ("0");  2 / 4: that form wherever the shapes allow (tests)
-WINOGRAD = {"0": False, "2": 2, "4": 4, "8": 8, "f2": "f2"}.get(os.environ.get("W2E_WINOGRAD", ""), "auto")
+# ---- Winograd F(4x4,3x3) forms of the same-resolution layers (include/w2e.h, K1w / K1g).  Two own kernels, no vendor GEMM:
+#   form 4      the GEMM form for the WIDE layers: w2e_wino_pack_input (V in MFMA operand order) -> w2e_wino_gemm (the 36 contractions on fp32
+#               MFMA, operands L2 -> registers, the output transform and the direct kernel's epilogues in its epilogue: M never reaches HBM)
+#   form FUSED  w2e_wino_fused for the narrow high-resolution layers (nothing transform-domain in HBM at all)
+# WINOGRAD (W2E_WINOGRAD, read once here):
+#   "auto"  per layer, what measures fastest: form 4 for K, N >= 128 at 16^2 ... 128^2 (K = N = 256 / 512), FUSED for 128 @ 256^2, 64 @ 512^2,
+#           32 @ 1024^2, the direct kernels for the rest (up-sampling layers, <= 8^2).  Rounding ~1e-5 relative (direct: 3e-7)
+#   False   direct kernels only ("0");  4 / 8: that form wherever the shapes allow (tests, tools)
+def _parse_winograd(v):
+    table = {"": "auto", "auto": "auto", "0": False, "4": 4, "8": 8}
+    if v not in table:  # (a typo used to mean "auto": a user asking for the exact direct kernels got the 1e-5 forms silently)
+        raise ValueError(f"W2E_WINOGRAD={v!r}: expected 'auto', '0' (direct kernels), '4' (GEMM form) or '8' (fused form)")
+    return table[v]
+
+
+WINOGRAD = _parse_winograd(os.environ.get("W2E_WINOGRAD", ""))
 WINO_LOG = None  # a list: every Winograd-form conv appends one line in the format of the library's tune_print (tests, tools/cfg_selections.py)
 
 
@@ -261,80 +268,59 @@ FUSED = 8  # form code of the fused F(4x4,3x3) kernel (w2e_wino_fused)
 
 
 def set_winograd(mode):
-    """mode: "auto" | "f2" | False | 2 | 4 | 8 (8: the fused F(4x4,3x3) kernel wherever its shapes allow)"""
+    """mode: "auto" | False | 4 | 8 (4: the GEMM form, 8: the fused F(4x4,3x3) kernel, each wherever its shapes allow)"""
     global WINOGRAD
-    if mode not in ("auto", "f2", False, 2, 4, 8):
-        raise ValueError("set_winograd: 'auto', 'f2', False, 2, 4 or 8")
+    if mode not in ("auto", False, 4, 8):
+        raise ValueError("set_winograd: 'auto', False, 4 or 8")
     WINOGRAD = mode
 
 
-FUSED_VERSION = "auto"  # the fused kernel's variants (include/w2e.h): 1 one workgroup per 32-tile block (N = 32 / 64; atomics for the fused dot);
-#                          2 persistent, loader + matrix waves (K a power of two >= 32; the fused dot as per-block partials); 3 = 2 with the raw
-#                          patch staged by LDS-DMA (K <= 256).  "auto": 3 where its shapes allow (32 @ 1024^2, batch 8 forward: 0.98 ms against
-#                          1.19 / 1.18 for 1 / 2 and 1.28 direct; 64 @ 512^2: 0.72 / 0.81 / 0.89 / 1.15), else 1, else 2
-FUSED_WGS = 0           # > 0: cap of the persistent grid of versions 2 / 3 (tests)
-
-
-def _fused_version(k, n, dot):
-    v1_ok, v2_ok = n in (32, 64), (k >= 32 and k & (k - 1) == 0)
-    v3_ok = v2_ok and k <= 256
-    if FUSED_VERSION == 1:
-        return 1 if v1_ok else 0
-    if FUSED_VERSION == 2:
-        return 2 if v2_ok else 0
-    if FUSED_VERSION == 3:
-        return 3 if v3_ok else 0
-    return 3 if v3_ok else (1 if v1_ok else (2 if v2_ok else 0))
+FUSED_WGS = 0           # > 0: cap of the fused kernel's persistent grid (tests)
+X_LIMIT = 2 ** 32 - 64  # bytes: the fused kernel addresses the whole input through ONE buffer descriptor
 
 
 def _fused_shape_ok(b, k, n, h, w, dot=False):
-    if not (b > 0 and k % 8 == 0 and n % 32 == 0 and h % 16 == 0 and w % 32 == 0 and b * (h // 16) * (w // 32) < 2 ** 31):
+    """w2e_wino_fused's shape rules (include/w2e.h, K1w).  It range-checks its loads against one descriptor over x, so it needs
+    x < 4 GB (total batch 32 of the 32 @ 1024^2 layer is 4 GiB: the merged [w; w_hat] pass reaches that at batch_size 16) -- past it
+    the selection falls back to the GEMM form or the direct kernel, which only needs one image under 4 GB."""
+    if not (b > 0 and n % 32 == 0 and h % 16 == 0 and w % 32 == 0 and b * (h // 16) * (w // 32) < 2 ** 31):
         return False
-    return _fused_version(k, n, dot) != 0
+    return 32 <= k <= 256 and k & (k - 1) == 0 and 4 * b * k * h * w < X_LIMIT
 
 
-def _wino_shape_ok(m, b, k, n, h, w, dot=True):
-    if h % m or w % m or b == 0 or b * max(k, n) >= 65536:
+def _gemm_shape_ok(b, k, n, h, w, dot=True):
+    """w2e_wino_gemm's shape rules (include/w2e.h, K1g)."""
+    if b <= 0 or k % 8 or n % 64 or h % 4 or w % 4:
         return False
-    tiles = (h // m) * (w // m)  # (the fused dot reduces over the lanes of a wave that share a plane)
-    return (not dot) or tiles % 64 == 0 or (m == 4 and tiles < 64 and tiles & (tiles - 1) == 0)
+    tiles = (h // 4) * (w // 4)
+    tp = (b * tiles + 31) & ~31
+    if 36 * k * tp * 4 >= X_LIMIT or 36 * k * n * 4 >= X_LIMIT or b * tiles >= 2 ** 30:
+        return False
+    return (not dot) or tiles % 32 == 0 or (tiles < 32 and tiles & (tiles - 1) == 0)  # (the fused dot reduces over half-wave segments)
 
 
 def _wino_form(x, k, n, h, w, dot_with):
-    """0 (direct kernel), 2 or 4 (the F(m x m, 3x3) form through the library GEMM) or FUSED (w2e_wino_fused) for one W2E_CONV_SAME call."""
+    """0 (direct kernel), 4 (the GEMM form: w2e_wino_pack_input + w2e_wino_gemm) or FUSED (w2e_wino_fused) for one W2E_CONV_SAME call."""
     if WINOGRAD is False:
         return 0
     b = x.shape[0]
+    dot = dot_with is not None
     if WINOGRAD == "auto":
         m = 4 if (k >= 128 and n >= 128 and 16 <= h <= 256 and 16 <= w <= 256) else 0
-        if k <= 128 and n <= 128 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w, dot_with is not None):
-            m = FUSED  # 128 @ 256^2 (0.62 ms fused against 0.70 through the GEMM), 64 @ 512^2, 32 @ 1024^2
-    elif WINOGRAD == "f2":
-        m = 2 if (k >= 256 and n >= 256 and 16 <= h <= 128 and 16 <= w <= 128) else 0
+        if k <= 128 and n <= 128 and h >= 256 and w >= 256 and _fused_shape_ok(b, k, n, h, w, dot):
+            m = FUSED  # 128 @ 256^2, 64 @ 512^2, 32 @ 1024^2
     else:
         m = WINOGRAD
     if m == FUSED:
-        if not _fused_shape_ok(b, k, n, h, w, dot_with is not None):
+        if not _fused_shape_ok(b, k, n, h, w, dot):
             return 0
-    elif not m or not _wino_shape_ok(m, b, k, n, h, w, dot_with is not None):
+    elif not m or not _gemm_shape_ok(b, k, n, h, w, dot):
         return 0
     if _lib.get_option("conv_precision") != 0:
         return 0
-    if _lib.get_option("deterministic") and not (m == FUSED and _fused_version(k, n, dot_with is not None) >= 2):
-        return 0  # (bit-reproducible mode: the library GEMM of the GEMM forms may reduce in a run-dependent order, and their fused dot
-        #            and version 1's use atomics; the persistent fused kernels sum their partials in a fixed order)
+    # (bit-reproducible mode keeps both forms: the fused kernel leaves per-block partials of its fused dot, the GEMM form per-segment
+    # partials and K-split slabs -- all summed in a fixed order, no atomics)
     return m if _lib.get_option("tune_cfg") < 0 else 0  # (a forced direct tile: tests, tools/layer_bench.py)
-
-
-def _wino_weights(wp, k, n, m):
-    """U [(m+2)^2,N,K] of a packed weight, built once and kept on the pack tensor (a pack is rebuilt, not edited, when its weight changes)."""
-    key = "_w2e_wino_u%d" % m
-    u = getattr(wp, key, None)
-    if u is None:
-        u = torch.empty(((m + 2) ** 2, n, k), device=wp.device, dtype=torch.float32)
-        call("w2e_wino_weights", ptr(wp), ptr(u), k, n, m, stream_ptr())
-        setattr(wp, key, u)
-    return u
 
 
 def _wino_weights_fused(wp, k, n):
@@ -346,41 +332,56 @@ def _wino_weights_fused(wp, k, n):
     return uf
 
 
+GEMM_SPLITS = 0  # > 0: force w2e_wino_gemm's K split (tests); 0: the library's plan
+
+
+def wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n, h, w, act_code=0, noise=None, noise_w=None, bias=None, slope=None,
+                   dot_with=None, dot=None):
+    """One same-resolution 3x3 conv in the F(4x4,3x3) GEMM form (K1g): w2e_wino_pack_input -> w2e_wino_gemm; `dot` [b,n] is accumulated
+    into (in a fixed order, no atomics) when dot_with is given."""
+    b = x.shape[0]
+    tp, sp, ws = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+    call("w2e_wino_gemm_plan", b, k, n, h, w, ctypes.byref(tp), ctypes.byref(sp), ctypes.byref(ws))
+    splits = sp.value
+    ws_floats = ws.value
+    if GEMM_SPLITS > 0 and GEMM_SPLITS != splits:
+        splits = min(GEMM_SPLITS, k // 8)
+        kcs = -(-(k // 8) // splits)
+        splits = -(-(k // 8) // kcs)
+        ws_floats = b * n * max(1, (h // 4) * (w // 4) // 32) + (splits * b * n * h * w if splits > 1 else 0)
+    if WINO_LOG is not None:
+        WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) gemm{', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
+                        f"36 x [{n}x{k}] x [{k}x{tp.value}], {splits} K split(s)")
+    vf = torch.empty(36 * k * tp.value, device=x.device, dtype=torch.float32)
+    work = torch.empty(ws_floats, device=x.device, dtype=torch.float32) if (splits > 1 or dot_with is not None) else None
+    st = stream_ptr()
+    call("w2e_wino_pack_input", ptr(x), ptr(in_scale), ptr(vf), b, k, h, w, tp.value, st)
+    call("w2e_wino_gemm", ptr(_wino_weights_fused(wp, k, n)), ptr(vf), ptr(out_scale), ptr(y), b, k, n, h, w, tp.value, splits, ptr(work),
+         act_code, ptr(noise), ptr(noise_w), ptr(bias), ptr(slope), ptr(dot_with), ptr(dot), st)
+
+
 def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot):
     b = x.shape[0]
+    noise = noise_w = bias = None
+    if act is not None:
+        noise, noise_w, bias = act
     if m == FUSED:
         if WINO_LOG is not None:
-            WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) fused v{_fused_version(k, n, dot_with is not None)}{', dot' if dot_with is not None else ''}) "
+            WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) fused{', dot' if dot_with is not None else ''}) "
                             f"K {k} N {n} {h}x{w} B {b} -> {b * (h // 16) * (w // 32)} blocks of 32 tiles")
-        noise = noise_w = bias = None
-        if act is not None:
-            noise, noise_w, bias = act
-        ver = _fused_version(k, n, dot_with is not None)
-        if dot_with is not None and ver >= 2:  # one partial per (spatial block, channel): summed here, in a fixed order
+        if dot_with is not None:  # one partial per (spatial block, channel): summed here, in a fixed order
             nblk = (h // 16) * (w // 32)
             part = torch.empty((b, n, nblk), device=x.device, dtype=torch.float32)
             call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
-                 0, None, None, None, None, ptr(dot_with), ptr(part), ver, FUSED_WGS, stream_ptr())
+                 0, None, None, None, None, ptr(dot_with), ptr(part), FUSED_WGS, stream_ptr())
             sums = torch.empty((b, n), device=x.device, dtype=torch.float32)  # (a kernel, not aten::sum: that one memsets under capture)
             call("w2e_channel_sums", ptr(part), None, ptr(sums), b, n, nblk, stream_ptr())
             dot.add_(sums)
             return
         call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
-             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), None, ptr(dot_with), ptr(dot), ver, FUSED_WGS, stream_ptr())
+             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), None, None, None, FUSED_WGS, stream_ptr())
         return
-    tiles = b * (h // m) * (w // m)
-    if WINO_LOG is not None:
-        WINO_LOG.append(f"modconv mode 0 (winograd F({m}x{m},3x3){', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
-                        f"{(m + 2) ** 2} x [{n}x{k}] x [{k}x{tiles}]")
-    u = _wino_weights(wp, k, n, m)
-    v = torch.empty(((m + 2) ** 2, k, tiles), device=x.device, dtype=torch.float32)
-    call("w2e_wino_input", ptr(x), ptr(in_scale), ptr(v), b, k, h, w, m, stream_ptr())
-    prod = torch.bmm(u, v)  # [P, N, tiles]
-    noise = noise_w = bias = None
-    if act is not None:
-        noise, noise_w, bias = act
-    call("w2e_wino_output", ptr(prod), ptr(out_scale), ptr(y), b, n, h, w, m, int(act is not None), ptr(noise), ptr(noise_w), ptr(bias),
-         None, ptr(dot_with), ptr(dot), stream_ptr())
+    wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n, h, w, int(act is not None), noise, noise_w, bias, None, dot_with, dot)
 
 
 def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None, out=None, dot_out=None):
@@ -405,12 +406,12 @@ def _modconv_raw(mode, x, wp, in_scale, out_scale, h, w, act=None, dot_with=None
         noise, noise_w, bias = act
     # algorithmic FLOPs: 2*K*N*9 per domain pixel (MACs actually needed; SURVEY 2.3 convention)
     form = _wino_form(x, k, n, h, w, dot_with) if mode == MODE_SAME else 0
-    sp = profiling.span("modconv3x3_wino%d" % (4 if form == FUSED else form) if form else "modconv3x3", 2.0 * b * k * n * 9 * h * w)
+    sp = profiling.span("modconv3x3_wino4" if form else "modconv3x3", 2.0 * b * k * n * 9 * h * w)
     if form:
         _modconv_wino(form, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, dot)
     else:
         call("w2e_modconv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n, h, w,
-             int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
+             y.shape[-1] if mode == MODE_UP else 0, int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), ptr(dot_with), ptr(dot), stream_ptr())
     if sp is not None:
         sp.end()
     return y, dot
@@ -591,8 +592,9 @@ class _StyledConv(torch.autograd.Function):
             # stride-2 conv that is the adjoint of conv_transpose2d
             gpre = _upfirdn2d_raw(gpre, blur_kernel, 2 * h + 1, 2 * w + 1, 1, 1, 2, 2, False)
         mode = MODE_DOWN if upsample else MODE_SAME
-        if _lib.get_option("deterministic"):
-            # the fused dot epilogue joins the workgroups of a (b, channel) with fp32 atomics; here instead: the unscaled
+        if _lib.get_option("deterministic") and not (mode == MODE_SAME and _wino_form(gpre, gpre.shape[1], cin, h, w, x)):
+            # (both Winograd forms sum the partials of their fused dot in a fixed order: they stay)
+            # the direct kernel's fused dot epilogue joins the workgroups of a (b, channel) with fp32 atomics; here instead: the unscaled
             # input gradient, its per-channel dot with x by a fixed-order wave reduction, then the out_scale
             raw, _ = _modconv_raw(mode, gpre, wp_b, d, None, h, w)
             gs = _channel_dot(raw, x, out=gs_out)

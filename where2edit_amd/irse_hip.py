@@ -19,7 +19,7 @@ _P = __import__("ctypes").c_void_p
 _L = __import__("ctypes").c_int64
 _F = __import__("ctypes").c_float
 PROTOS = {
-    "w2e_conv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "w2e_conv3x3": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "w2e_affine_act_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "w2e_affine_act_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "w2e_channel_sums": (_I, [_P, _P, _P, _I, _I, _L, _P]),
@@ -43,39 +43,31 @@ FUSED_ENCODER = os.environ.get("W2E_FUSED_ENCODER", "1") != "0"  # (A/B aid: the
 
 
 def _wino_form(b, k, n, h, w):
-    """The Winograd form (functional.py, K1w) of one stride-1 3x3 conv of the IR-SE50 / e4e encoders, or 0: F(4x4,3x3) where the
-    image divides into 4x4 tiles, F(2x2,3x3) for the 14^2 stages, the direct kernel for the 64-channel stages, for odd sizes (7^2) and
-    where the transform-domain GEMMs are too small to pay for three launches (profiles/r03_irse_shapes.txt)."""
-    if K.WINOGRAD is False or K.WINOGRAD == "f2" and (h % 2 or w % 2):
+    """The Winograd F(4x4,3x3) form (functional.py, K1w / K1g) of one stride-1 3x3 conv of the IR-SE50 / e4e encoders, or 0: the fused kernel
+    for the narrow high-resolution stages, the GEMM form (own MFMA contraction, output transform in its epilogue) where the image divides
+    into 4x4 tiles and the channel counts allow, the direct kernel for the 64-channel 112^2-network stages, for 14^2 / 7^2 and where the
+    call is too small to pay for two launches (profiles/r03_irse_shapes.txt, r04_irse_shapes.txt)."""
+    if K.WINOGRAD is False:
         return 0
-    # the fused kernel (no transform-domain tensor in HBM, no GEMM call): where its shapes allow, up to 128 input channels it beats
-    # both the direct kernel and the GEMM forms (64 -> 64 @ 256^2, batch 8: 191 us against 350 / 353; 128 -> 256 @ 64^2: 86 / 171 / 114)
-    if FUSED_ENCODER and K.WINOGRAD in ("auto", K.FUSED) and K._fused_shape_ok(b, k, n, h, w) and K._fused_version(k, n, False) == 3 \
+    if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0:
+        return 0
+    # the fused kernel (no transform-domain tensor in HBM): where its shapes allow, up to 128 input channels it beats both the direct
+    # kernel and the GEMM form (64 -> 64 @ 256^2, batch 8: 191 us against 350 / 353; 128 -> 256 @ 64^2: 86 / 171 / 114)
+    if FUSED_ENCODER and K.WINOGRAD in ("auto", K.FUSED) and K._fused_shape_ok(b, k, n, h, w) \
             and (K.WINOGRAD == K.FUSED or (k <= 128 and 18.0 * b * k * n * h * w >= 3e9)):
-        return K.FUSED if (_lib.get_option("conv_precision") == 0 and _lib.get_option("tune_cfg") < 0) else 0
+        return K.FUSED
     if K.WINOGRAD == K.FUSED:
         return 0
-    if K.WINOGRAD in (2, 4):
-        m = K.WINOGRAD
-    elif K.WINOGRAD == "f2":
-        m = 2
-    else:
-        m = 4 if (h % 4 == 0 and w % 4 == 0) else 2
-    # measured (profiles/r03_irse_shapes.txt): the forms win from 128 channels on one side and ~3 GFLOP of direct work per call
-    # (below it three launches cost more than the GEMM saves); the library's GEMM for F(2x2) at 256 -> 512 @ 14^2 is the exception
-    if K.WINOGRAD in ("auto", "f2") and not (k >= 64 and max(k, n) >= 128 and 18.0 * b * k * n * h * w >= 3e9 and (m == 4 or n <= 256)):
+    # measured: the form wins from 128 channels on one side and ~3 GFLOP of direct work per call
+    if K.WINOGRAD == "auto" and not (k >= 64 and max(k, n) >= 128 and 18.0 * b * k * n * h * w >= 3e9):
         return 0
-    if not K._wino_shape_ok(m, b, k, n, h, w, dot=False):
-        return 0
-    if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0 or _lib.get_option("deterministic"):
-        return 0  # (deterministic: the library GEMM may reduce in a run-dependent order)
-    return m
+    return 4 if K._gemm_shape_ok(b, k, n, h, w, dot=False) else 0
 
 
 def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None, out=None, form=None):
     """w2e_conv3x3.  h,w: input size for SAME / UP, output size for DOWN.  in_scale [B,K] / out_scale [B,N] / bias, slope [N].
     `out`: a contiguous [B,n_out,h,w] tensor to write (SAME / DOWN).  `form`: None = the library's / _wino_form's choice;
-    0 / 2 / 4 force the direct kernel / a Winograd form (tools/irse_shapes.py)."""
+    0 / 4 / 8 force the direct kernel / a Winograd form (tools/irse_shapes.py)."""
     b, k = x.shape[0], x.shape[1]
     if mode == K.MODE_SAME and b > 0:
         m = _wino_form(b, k, n_out, h, w) if form is None else form
@@ -83,22 +75,14 @@ def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out
             y = out if out is not None else torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
             if out is not None:
                 assert out.shape == (b, n_out, h, w) and out.is_contiguous()
-        if m == K.FUSED:
-            if K.WINO_LOG is not None:
-                K.WINO_LOG.append(f"conv3x3 (winograd F(4x4,3x3) fused v3) K {k} N {n_out} {h}x{w} B {b}")
-            call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(K._wino_weights_fused(wp, k, n_out)), ptr(out_scale), ptr(y), b, k, n_out, h, w,
-                 2 if (bias is not None or slope is not None) else 0, None, None, ptr(bias), ptr(slope), None, None, 3, K.FUSED_WGS, stream_ptr())
-            return y
-        if m:
-            tiles = b * (h // m) * (w // m)
-            if K.WINO_LOG is not None:
-                K.WINO_LOG.append(f"conv3x3 (winograd F({m}x{m},3x3)) K {k} N {n_out} {h}x{w} B {b} -> {(m + 2) ** 2} x [{n_out}x{k}] x [{k}x{tiles}]")
-            u = K._wino_weights(wp, k, n_out, m)
-            v = torch.empty(((m + 2) ** 2, k, tiles), device=x.device, dtype=torch.float32)
-            call("w2e_wino_input", ptr(x), ptr(in_scale), ptr(v), b, k, h, w, m, stream_ptr())
-            prod = torch.bmm(u, v)
-            call("w2e_wino_output", ptr(prod), ptr(out_scale), ptr(y), b, n_out, h, w, m, 2 if (bias is not None or slope is not None) else 0,
-                 None, None, ptr(bias), ptr(slope), None, None, stream_ptr())
+            epi = 2 if (bias is not None or slope is not None) else 0
+            if m == K.FUSED:
+                if K.WINO_LOG is not None:
+                    K.WINO_LOG.append(f"conv3x3 (winograd F(4x4,3x3) fused) K {k} N {n_out} {h}x{w} B {b}")
+                call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(K._wino_weights_fused(wp, k, n_out)), ptr(out_scale), ptr(y), b, k, n_out, h, w,
+                     epi, None, None, ptr(bias), ptr(slope), None, None, K.FUSED_WGS, stream_ptr())
+            else:
+                K.wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n_out, h, w, epi, None, None, bias, slope)
             return y
     if out is not None:
         assert mode != K.MODE_UP and out.shape == (b, n_out, h, w) and out.is_contiguous()
@@ -107,8 +91,8 @@ def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out
         y = torch.empty((b, n_out, 2, 2, h + 1, K.planar_pitch(w)), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((b, n_out, h, w), device=x.device, dtype=torch.float32)
-    call("w2e_conv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n_out, h, w, down_pad, ptr(bias), ptr(slope),
-         stream_ptr())
+    call("w2e_conv3x3", mode, ptr(x), ptr(wp), ptr(in_scale), ptr(out_scale), ptr(y), b, k, n_out, h, w,
+         y.shape[-1] if mode == K.MODE_UP else 0, down_pad, ptr(bias), ptr(slope), stream_ptr())
     return y
 
 
@@ -123,7 +107,8 @@ def affine_act_bwd(gy, y, a, slope, batch, channels, height, width, planar=False
     if planar and tuple(gy.shape[-4:]) != (2, 2, height // 2 + 1, K.planar_pitch(width // 2)):
         raise RuntimeError(f"affine_act_bwd: the phase-planar gradient of a {height}x{width} image must end in "
                            f"[2,2,{height // 2 + 1},{K.planar_pitch(width // 2)}] (W2E_PLANAR_PITCH), got {tuple(gy.shape)}")
-    call("w2e_affine_act_bwd", ptr(gy), ptr(y), ptr(a), ptr(slope), ptr(gx), batch, channels, height, width, int(planar), stream_ptr())
+    call("w2e_affine_act_bwd", ptr(gy), ptr(y), ptr(a), ptr(slope), ptr(gx), batch, channels, height, width,
+         gy.shape[-1] if planar else 0, stream_ptr())  # (the pitch the tensor WAS allocated with: the library checks it against its own)
     return gx
 
 
@@ -269,7 +254,7 @@ class _IRUnit(torch.autograd.Function):
                 call("w2e_shortcut_add_bwd", ptr(gx), ptr(gs), n, cin, h, w, 1, 0, stream_ptr())
             else:
                 ts = conv3x3(gout, p.wsb, cin, oh, ow, mode=K.MODE_UP, in_scale=a_s)
-                call("w2e_shortcut_add_bwd", ptr(gx), ptr(ts), n, cin, h, w, 1, 1, stream_ptr())
+                call("w2e_shortcut_add_bwd", ptr(gx), ptr(ts), n, cin, h, w, 1, ts.shape[-1], stream_ptr())
         else:
             call("w2e_shortcut_add_bwd", ptr(gx), ptr(gout), n, cin, oh, ow, s, 0, stream_ptr())
         return gx_full, None, None
