@@ -16,8 +16,10 @@ per-GPU batch, so that a 1 -> N ratio can be taken at equal per-GPU work.
 Weights are random-init of the real architectures (no network for checkpoints), data is synthetic.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the ModulatedConv2d 3x3 convs (direct MFMA kernels + the Winograd-form layers): algorithmic FLOPs / HIP-event time,
-                  vs fp32-MFMA peak; `executed` / `direct` / `winograd` split it (the Winograd forms execute 1/4 of their algorithmic FLOPs)
+  roofline     -- the ModulatedConv2d 3x3 convs of the step (direct MFMA kernels + the two Winograd F(4x4,3x3) forms, all own kernels):
+                  FLOPs the matrix pipes EXECUTE / HIP-event time vs the fp32-MFMA peak (`frac` <= 1 by construction); `dominant_kernel`
+                  = w2e::modconv_kernel alone; `effective_tflops` = the direct-form (algorithmic) FLOPs of the same calls over the same time
+                  (the Winograd forms execute 1/4 of them) -- an effective rate, not a roofline fraction
   cpu_baseline -- the CPU oracle (a port of the reference algorithm) timed on this box's host cores
 """
 import argparse
@@ -270,7 +272,7 @@ def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0, world
             return len(times), stable
 
 
-def bench_config5(args, rank, world, device):
+def measure_config5(args, rank, world, device, batch):
     """BASELINE configs[4] on this rank's share of the images: 256^2 image -> e4e -> S codes -> features -> region-attention
     net (mask + new codes) -> masked 1024^2 generator -> CLIP features (where2edit_amd.demo_pipeline.invert_and_edit).
     Inference: every rank works on its own images, nothing is exchanged.  Random-init weights of the real architectures."""
@@ -288,8 +290,8 @@ def bench_config5(args, rank, world, device):
     net = FullSpaceMapperFEATClusterLinStyle_Net(18, 1024, 512, attention_layer=13, cluster_layer=13, channel_multiplier=2,
                                                  clusters=20, cluster_dim=576).to(device).eval().requires_grad_(False)
     gen = torch.Generator().manual_seed(100 + rank)
-    imgs = (torch.rand(args.batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
-    text, att = (torch.randn(args.batch, 512, generator=gen) * 0.3).to(device), (torch.randn(args.batch, 512, generator=gen) * 0.3).to(device)
+    imgs = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+    text, att = (torch.randn(batch, 512, generator=gen) * 0.3).to(device), (torch.randn(batch, 512, generator=gen) * 0.3).to(device)
     with torch.no_grad():  # random-init net: logit(0.8) as the bias and 20 pixels of the first batch's layer-13 features as the
         net.initial_bias.fill_(1.3863)  # cluster centres give a mixed (not all-0 / all-1) thresholded mask, as in make_mask()
         _, _, styles0 = g([e4e(imgs)], input_is_latent=True, return_latents=True, randomize_noise=False)
@@ -335,20 +337,29 @@ def bench_config5(args, rank, world, device):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
-        torch.distributed.destroy_process_group()
-    if rank != 0:
-        return
     finite = bool(torch.isfinite(out["img_gen"]).all())
     if not finite:
         raise SystemExit("non-finite output")
+    return {"value": batch * world * args.steps / dt, "unit": "images/s", "ms_per_step": 1e3 * dt / args.steps, "batch": batch,
+            "workload": f"BASELINE configs[4]: e4e encode -> S codes -> 26 features -> region-attention net (cluster-pooled mask, new codes) -> "
+                        f"masked FFHQ-1024 generator -> CLIP features (show_demo/try_demo.py:93-157), batch {batch}/GPU, no backward",
+            "stabilise_steps": n_stab, "stabilised": ok, "mask_mean": float(out["mask"].mean()), "hip_graph": use_graph,
+            "hip_graph_note": graph_note}
+
+
+def bench_config5(args, rank, world, device):
+    r = measure_config5(args, rank, world, device, args.batch)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
     print(json.dumps({
-        "metric": "1024^2 edited images/sec, invert-and-edit inference pipeline (BASELINE configs[4])", "value": args.batch * world * args.steps / dt,
-        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "metric": "1024^2 edited images/sec, invert-and-edit inference pipeline (BASELINE configs[4])", "value": r["value"],
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"e4e encode -> S codes -> 26 features -> region-attention net (cluster-pooled mask, new codes) -> masked "
-                               f"FFHQ-1024 generator -> CLIP features (show_demo/try_demo.py:93-157), batch {args.batch}/GPU, no backward",
-                   "global_batch": args.batch * world, "parallelism": f"replicas x{world}", "stabilise_steps": n_stab, "stabilised": ok,
-                   "mask_mean": float(out["mask"].mean()), "hip_graph": use_graph, "hip_graph_note": graph_note}}), flush=True)
+        "config": {"workload": r["workload"], "global_batch": args.batch * world, "parallelism": f"replicas x{world}",
+                   "stabilise_steps": r["stabilise_steps"], "stabilised": r["stabilised"], "mask_mean": r["mask_mean"],
+                   "hip_graph": r["hip_graph"], "hip_graph_note": r["hip_graph_note"]}}), flush=True)
 
 
 def main():
@@ -374,6 +385,7 @@ def main():
                          "show the per-kernel times the roofline is quoted on)")
     ap.add_argument("--no-n1-b8", action="store_true", help="skip the extra batch-8 measurement (`n1_b8`) of a default N=1 run")
     ap.add_argument("--no-config3", action="store_true", help="skip the extra BASELINE configs[2] measurement of a default N=1 run")
+    ap.add_argument("--no-config5", action="store_true", help="skip the extra BASELINE configs[4] measurement (batch 4 = 32 images / 8 GPUs) of a default N=1 run")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="replay the step as one captured hipGraph (Coach.capture_step) instead of ~330 eager launches; the per-kernel "
                          "HIP-event roofline is then taken from eager steps run right after the timed region (same kernels, same "
@@ -629,6 +641,14 @@ def main():
                           "workload": "BASELINE configs[2]: FFHQ-1024 mapper step with the region-attention mask (cluster-pooled, "
                                       "thresholded, blurred; run_attention.py:754-884) blended at layer 13 + clip_loss + id_loss "
                                       "(IR-SE50), batch 8, 1 GPU; same as `bench.py --workload 3 --batch 8`"}
+    if world == 1 and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config5:
+        # BASELINE configs[4] (invert-and-edit inference) at ONE GPU's share of its 32 images over 8 GPUs, in the same run so that a
+        # driver-run figure exists for it.  Reported beside the headline, never as `value`.
+        coach = coach3 = None
+        torch.cuda.empty_cache()
+        out["config5"] = measure_config5(args, rank, world, device, 4)
+        out["config5"]["same_as"] = "`bench.py --workload 5 --batch 4`"
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size)
     print(json.dumps(out), flush=True)

@@ -29,12 +29,14 @@ def assert_close(a, b, tol, what=""):
 GRAD_ERRORS = []  # (what, max-norm relative error, cosine) of every assert_grad_close call: printed at the end of the run (conftest)
 
 
-def assert_grad_close(a, b, what="", tol=1e-2, cos_min=0.9999):
+def assert_grad_close(a, b, what="", tol=5e-3, cos_min=0.9999):
     """Gradients THROUGH the generator: fp32 autograd of this network carries discrete noise from
     LeakyReLU kinks (a pre-activation within rounding of 0 flips its slope 0.2<->1).  Measured in the
     build container: the reference's own fp32 gradient differs from its float64 gradient by up to 3e-3
     (max-norm relative) on some seeds and 7e-7 on others.  So gradient parity is stated as max-norm
-    relative error <= 1e-2 AND cosine similarity >= 0.9999."""
+    relative error <= 5e-3 AND cosine similarity >= 0.9999 (round 4: down from 1e-2; the largest error any
+    end-to-end comparison of the suite shows is 1.7e-3, the 1024^2 steps 1.2e-4 ... 3.1e-4 -- the table the
+    run prints, profiles/rNN_gpu_tests.log)."""
     a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
     e = rel_err(a, b)
     cos = torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)

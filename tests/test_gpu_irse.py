@@ -143,6 +143,16 @@ def test_e4e_encoder_on_hip_matches_reference_fixture():
                     assert_close(t[:, ::8, ::4, ::4], g[f"e4e.{key}_strided"], 1e-4, key)
             w2 = net(torch.cat([x, x.flip(3)]))  # batch 2
             assert_close(w2[:1], g[name + ".w"], 1e-4, name + " batch-2, sample 0")
+            # batch 4 (one GPU's share of BASELINE configs[4]): the work-gated Winograd forms of the stride-1 convs run here, not at batch 1
+            from where2edit_amd import functional as KF
+            KF.WINO_LOG = []
+            try:
+                w4 = net(torch.cat([x.flip(2), x.flip(3), x, x.flip(2).flip(3)]))
+            finally:
+                log, KF.WINO_LOG = KF.WINO_LOG, None
+            assert sum("fused" in l for l in log) >= 4 and sum("gemm" in l for l in log) >= 4, log
+            assert_close(w4[2:3], g[name + ".w"], 1e-4, name + " batch-4, sample 2")
+            assert_close(w4[1:2], w2[1:2], 1e-4, name + " batch-4 sample 1 == batch-2 sample 1")
 
 
 @pytest.mark.parametrize("shape,out", [((2, 16, 16, 16), (32, 32)), ((1, 5, 7, 9), (20, 31)), ((3, 8, 32, 32), (64, 64))])
@@ -159,9 +169,13 @@ def test_upsample_add_kernel_equals_bilinear_interpolate(shape, out):
     assert_close(got, ref, 2e-6, "upsample + add")
 
 
-def test_config5_invert_and_edit_pipeline_matches_oracle():
-    """BASELINE configs[4] end to end for one image: e4e -> S codes -> features -> region-attention net -> masked 1024^2
-    generator (show_demo/try_demo.py:93-157), every stage against the oracle composition."""
+@pytest.mark.parametrize("bsz", [1, 4])
+def test_config5_invert_and_edit_pipeline_matches_oracle(bsz):
+    """BASELINE configs[4] end to end -- e4e -> S codes -> features -> region-attention net -> masked 1024^2 generator
+    (show_demo/try_demo.py:93-157), every stage against the oracle composition -- for one image and at the batch one GPU of the
+    8-GPU configuration sees (32 / 8 = 4): the encoder's kernel selection is gated on the work per call (irse_hip._wino_form), so at
+    batch 4 its 64- / 128-channel stages take the fused Winograd kernel and its 256- / 512-channel ones the GEMM form where batch 1
+    keeps the direct kernel for most of them; the log of the forms that ran is asserted."""
     import make_golden_attention as MA
     import make_golden_e4e as ME
     from make_golden import CLIP_TINY as c
@@ -194,8 +208,8 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
                                                  clusters=k, cluster_dim=576)
     msd = MA.net_state_dict(net)
     msd["initial_bias"] = torch.tensor([0.9])  # about half of the 20 cluster means pass the 0.8 threshold
-    img = seeded.tensor("cfg5.img", (1, 3, 256, 256), 0.5)
-    text, att_text = seeded.tensor("cfg5.text", (1, edim), 0.3), seeded.tensor("cfg5.att", (1, edim), 0.3)
+    img = seeded.tensor("cfg5.img", (bsz, 3, 256, 256), 0.5)
+    text, att_text = seeded.tensor("cfg5.text", (bsz, edim), 0.3), seeded.tensor("cfg5.att", (bsz, edim), 0.3)
     # oracle, stage by stage
     with torch.no_grad():
         w_o = OE.encoder4editing(esd, img)
@@ -217,9 +231,20 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
                                               attention_layer=att, attention_map=mask_o, feature_map=feats_o)
         fo = OC.encode_image(csd, OO.clip_preprocess(gen_o, size))
     net.load_state_dict(msd, strict=True)
-    out = invert_and_edit(img.to(DEV), e4e.to(DEV).requires_grad_(False), g.to(DEV).requires_grad_(False),
-                          CLIPLoss(opts, model=clip).to(DEV), net.to(DEV).requires_grad_(False), text.to(DEV), att_text.to(DEV),
-                          attention_layer=att)
+    from where2edit_amd import functional as KF
+    KF.WINO_LOG = []
+    try:
+        out = invert_and_edit(img.to(DEV), e4e.to(DEV).requires_grad_(False), g.to(DEV).requires_grad_(False),
+                              CLIPLoss(opts, model=clip).to(DEV), net.to(DEV).requires_grad_(False), text.to(DEV), att_text.to(DEV),
+                              attention_layer=att)
+    finally:
+        log, KF.WINO_LOG = KF.WINO_LOG, None
+    enc = [l for l in log if l.startswith("conv3x3")]
+    n_fused, n_gemm = sum("fused" in l for l in enc), sum("gemm" in l for l in enc)
+    print(f"config 5, batch {bsz}: encoder convs on the fused Winograd kernel: {n_fused}, on the GEMM form: {n_gemm}; generator layers: "
+          f"{sum(l.startswith('modconv') for l in log)}")
+    if bsz >= 4:  # (the forms the measured configuration runs are the ones this comparison covers)
+        assert n_fused >= 4 and n_gemm >= 4, enc
     assert_close(out["latents"], w_o, 1e-4, "e4e W+")
     assert_close(out["img_orig"], img_o, 1e-4, "img_orig")
     assert 0.02 < float((mask_o > 0).float().mean()) < 0.98, "degenerate mask: the test would not exercise the blend"
@@ -234,7 +259,7 @@ def test_config5_invert_and_edit_pipeline_matches_oracle():
                                   attention_layer=att)
     rep = run(img.to(DEV), text.to(DEV), att_text.to(DEV))
     for key in ("latents", "img_orig", "mask", "img_gen", "features_gen"):
-        assert_close(rep[key], out[key], 1e-5, f"graph replay: {key}")  # (split-K joins by fp32 atomics: run-to-run rounding)
+        assert_close(rep[key], out[key], 1e-5, f"graph replay: {key}")  # (the direct kernels' split-K joins by fp32 atomics: run-to-run rounding)
 
 
 @pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 128, 28, 28), (4, 2, 256, 256, 28, 28), (4, 1, 64, 64, 112, 112), (4, 5, 128, 64, 56, 28),
