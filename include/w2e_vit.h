@@ -80,6 +80,22 @@ int w2e_attn2_fwd(const float* qkv, int nsplit, int64_t slab, const float* bias,
 int w2e_attn2_bwd(const float* qkv, int nsplit, int64_t slab, const float* bias, const float* gout, int gsplit, int64_t gslab,
                   float* gqkv, int batch, int seq, int heads, void* stream);
 
+/* ---- the scalar tail of a mapper step (csrc/losstail.hip): ~37 [B,T]- / [B,18,512]-sized stock launches as four -------------------
+ * criteria/clip_loss.py:16 + the tail of OpenAI clip.model.CLIP.forward: out[b,t] = exp(*logit_scale) * <f_b, t_t> / (|f_b| |t_t|)
+ * (feat [B,D], text [T,D], logit_scale a DEVICE scalar holding the log of the scale); similarity != 0: out = 1 - that / 100 (the
+ * loss's similarity).  bwd: the gradient to feat (text and the scale are frozen on this path). */
+int w2e_clip_logits_fwd(const float* feat, const float* text, const float* logit_scale, float* out, int batch, int n_text, int dim,
+                        int similarity, void* stream);
+int w2e_clip_logits_bwd(const float* gout, const float* feat, const float* text, const float* logit_scale, float* gfeat, int batch,
+                        int n_text, int dim, int similarity, void* stream);
+/* mapper/training/coach.py:223-245 for the clip + latent-L2 terms: out3 = { clip_lambda * mean(sim) + l2_lambda * MSE(w_hat, w),
+ * mean(sim), MSE(w_hat, w) } (sim: n_sim floats; w_hat, w: n_w floats; either count may be 0).  bwd: g_sim[i] = g * clip_lambda /
+ * n_sim, g_what = g * l2_lambda * 2 (w_hat - w) / n_w with g = *g_loss (a device scalar); g_sim / g_what may be NULL. */
+int w2e_step_loss_fwd(const float* sim, int n_sim, const float* w_hat, const float* w, int64_t n_w, float clip_lambda, float l2_lambda,
+                      float* out3, void* stream);
+int w2e_step_loss_bwd(const float* g_loss, int n_sim, const float* w_hat, const float* w, int64_t n_w, float clip_lambda, float l2_lambda,
+                      float* g_sim, float* g_what, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

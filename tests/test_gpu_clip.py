@@ -224,3 +224,39 @@ def test_mlp_up_split_paths_vs_torch():
         wt = torch.randn(3072, 768, generator=g).to(DEV) * 0.05
         s = torch.sigmoid(1.702 * href)
         assert_close(V._mlp_up_grad(gy, wt, h), (gy.double() @ wt.double().t()) * (s * (1 + 1.702 * href * (1 - s))), 1e-5, "gelu-grad")
+
+
+@pytest.mark.parametrize("b,t,d", [(4, 1, 512), (3, 5, 200), (8, 2, 768)])
+def test_fused_loss_tail_equals_the_stock_composition(b, t, d):
+    """csrc/losstail.hip: (1) the tail of CLIP.forward / CLIPLoss.forward -- normalise, exp(logit_scale), cosine logits, 1 - ./100 -- and
+    (2) coach.calc_loss's clip_lambda * mean + l2_lambda * MSE as one launch each way, against the stock-op composition in float64
+    (clip_loss.py:16, coach.py:223-245): values, the gradient to the image features and to w_hat."""
+    from where2edit_amd import vit_hip as V
+    g = torch.Generator().manual_seed(b * 100 + t * 10 + d)
+    feat = torch.randn(b, d, generator=g).to(DEV).requires_grad_(True)
+    text = torch.randn(t, d, generator=g).to(DEV)
+    ls = torch.tensor(2.6593, device=DEV)
+    w, w_hat = torch.randn(b, 18, 512, generator=g).to(DEV), torch.randn(b, 18, 512, generator=g).to(DEV).requires_grad_(True)
+    for sim_flag in (False, True):
+        out = V.clip_logits(feat, text, ls, similarity=sim_flag)
+        fd = feat.detach().double().requires_grad_(True)
+        ref = ls.double().exp() * (fd / fd.norm(dim=1, keepdim=True)) @ (text.double() / text.double().norm(dim=1, keepdim=True)).t()
+        ref = 1 - ref / 100 if sim_flag else ref
+        assert_close(out, ref, 1e-5, "logits" if not sim_flag else "similarity")
+        r = torch.randn(b, t, generator=g).to(DEV)
+        (gf,) = torch.autograd.grad((out * r).sum(), feat)
+        (gr,) = torch.autograd.grad((ref * r.double()).sum(), fd)
+        assert_close(gf, gr, 1e-5, "d logits / d features")
+    sim = V.clip_logits(feat, text, ls, similarity=True)
+    loss, l_clip, l_l2 = V.step_loss(sim, w_hat, w, 1.0, 0.8)
+    assert not l_clip.requires_grad and not l_l2.requires_grad and loss.requires_grad
+    wd = w_hat.detach().double().requires_grad_(True)
+    fd = feat.detach().double().requires_grad_(True)
+    sim_ref = 1 - ls.double().exp() * (fd / fd.norm(dim=1, keepdim=True)) @ (text.double() / text.double().norm(dim=1, keepdim=True)).t() / 100
+    ref_clip, ref_l2 = sim_ref.mean(), torch.nn.functional.mse_loss(wd, w.double())
+    ref = ref_clip * 1.0 + ref_l2 * 0.8
+    assert_close(loss, ref, 1e-5, "loss"), assert_close(l_clip, ref_clip, 1e-5, "loss_clip"), assert_close(l_l2, ref_l2, 1e-5, "loss_l2")
+    loss.backward()
+    ref.backward()
+    assert_close(w_hat.grad, wd.grad, 1e-5, "d loss / d w_hat")
+    assert_close(feat.grad, fd.grad, 1e-5, "d loss / d features (through both fused nodes)")

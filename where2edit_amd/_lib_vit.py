@@ -18,6 +18,10 @@ PROTOS = {
     "w2e_layernorm_bwd_part": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "w2e_attn2_fwd": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P]),
     "w2e_attn2_bwd": (_I, [_P, _I, _L, _P, _P, _I, _L, _P, _I, _I, _I, _P]),
+    "w2e_clip_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_clip_logits_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_step_loss_fwd": (_I, [_P, _I, _P, _P, _L, _F, _F, _P, _P]),
+    "w2e_step_loss_bwd": (_I, [_P, _I, _P, _P, _L, _F, _F, _P, _P, _P]),
 }
 
 

@@ -43,5 +43,7 @@ class CLIPLoss(torch.nn.Module):
 
     def forward(self, image, text):
         image = self.preprocess(image)
+        if hasattr(self.model, "logits_per_image"):  # the package's CLIP: normalise, scale, product and 1 - ./100 in one launch
+            return self.model.logits_per_image(image, text, similarity=True)
         similarity = 1 - self.model(image, text)[0] / 100
         return similarity

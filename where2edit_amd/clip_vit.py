@@ -154,6 +154,20 @@ class CLIP(nn.Module):
         self._text_cache = None  # new weights: the cached text features are stale
         return super().load_state_dict(*args, **kwargs)
 
+    def logits_per_image(self, image, text, similarity=False):
+        """forward()[0] -- or, `similarity`, the loss's 1 - that / 100 (criteria/clip_loss.py:16) -- with the normalisations, the scale
+        and the product as one launch when only the image carries a gradient (vit_hip.clip_logits); else forward()'s composition."""
+        from . import vit_hip
+        text_frozen = not any(p.requires_grad for p in self.transformer.parameters())
+        image_features = self.encode_image(image)
+        text_features = self.encode_text_cached(text) if text_frozen else self.encode_text(text)
+        if text_frozen and vit_hip.clip_logits_ok(image_features, text_features, self.logit_scale):
+            return vit_hip.clip_logits(image_features, text_features, self.logit_scale, similarity)
+        image_features = image_features / image_features.norm(dim=1, keepdim=True)
+        text_features = text_features / text_features.norm(dim=1, keepdim=True)
+        logits = self.logit_scale.exp() * image_features @ text_features.t()
+        return 1 - logits / 100 if similarity else logits
+
     def forward(self, image, text):
         image_features = self.encode_image(image)
         text_features = self.encode_text_cached(text) if not any(p.requires_grad for p in self.transformer.parameters()) \

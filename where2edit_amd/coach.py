@@ -21,6 +21,9 @@ from .ranger import Ranger
 from .styleclip_mapper import StyleCLIPMapper
 
 
+FUSED_LOSS_TAIL = os.environ.get("W2E_FUSED_LOSS_TAIL", "1") != "0"  # (A/B aid: "0" keeps the stock-op composition of calc_loss)
+
+
 class Coach:
     def __init__(self, opts, net=None, clip_loss=None, id_loss=None, text_inputs=None, device=None, data_parallel=False):
         self.opts = opts
@@ -153,6 +156,18 @@ class Coach:
             loss_dict["loss_id"] = loss_id.detach()
             loss_dict["id_improve"] = sim_improvement
             loss = loss_id * self.opts.id_lambda
+        s_space = getattr(self.opts, "work_in_stylespace", False)
+        if self.opts.clip_lambda > 0 and self.opts.latent_l2_lambda > 0 and not s_space and torch.is_tensor(w_hat) and w_hat.is_cuda \
+                and w_hat.dtype == torch.float32 and FUSED_LOSS_TAIL:
+            # the clip and latent-L2 terms and their weighted sum as ONE launch (vit_hip.step_loss; backward: one more) instead of the
+            # mean / mse_loss / mul / add chain and its autograd mirror
+            from . import vit_hip
+            sim = self.clip_loss(x_hat, self.text_inputs)
+            tail, loss_dict["loss_clip"], loss_dict["loss_l2_latent"] = vit_hip.step_loss(sim, w_hat, w, self.opts.clip_lambda,
+                                                                                            self.opts.latent_l2_lambda)
+            loss = tail if self.opts.id_lambda <= 0 else loss + tail
+            loss_dict["loss"] = loss.detach()
+            return loss, loss_dict
         if self.opts.clip_lambda > 0:
             loss_clip = self.clip_loss(x_hat, self.text_inputs).mean()
             loss_dict["loss_clip"] = loss_clip.detach()

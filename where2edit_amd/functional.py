@@ -374,9 +374,9 @@ def _modconv_wino(m, x, wp, in_scale, out_scale, y, k, n, h, w, act, dot_with, d
             part = torch.empty((b, n, nblk), device=x.device, dtype=torch.float32)
             call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
                  0, None, None, None, None, ptr(dot_with), ptr(part), FUSED_WGS, stream_ptr())
-            sums = torch.empty((b, n), device=x.device, dtype=torch.float32)  # (a kernel, not aten::sum: that one memsets under capture)
-            call("w2e_channel_sums", ptr(part), None, ptr(sums), b, n, nblk, stream_ptr())
-            dot.add_(sums)
+            # (a kernel, not aten::sum: that one memsets under capture.)  `dot` arrives zeroed and nothing else adds to it before this
+            # call returns -- the partial sums ARE its value: written in place (round 3 summed into a temporary and added that: 2 more launches)
+            call("w2e_channel_sums", ptr(part), None, ptr(dot), b, n, nblk, stream_ptr())
             return
         call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(_wino_weights_fused(wp, k, n)), ptr(out_scale), ptr(y), b, k, n, h, w,
              int(act is not None), ptr(noise), ptr(noise_w), ptr(bias), None, None, None, FUSED_WGS, stream_ptr())

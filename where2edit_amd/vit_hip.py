@@ -421,3 +421,81 @@ def vision_forward(vit, image):
             x = resblock_forward(blk, x, vit.heads, arena)
     x = layer_norm(x[:, 0, :], vit.ln_post)
     return linear(x, vit.proj.t())  # [B,768] x [768,512]
+
+
+# ---------------------------------------------------------------------------------------------- the scalar tail of a step
+class _ClipLogits(torch.autograd.Function):
+    """exp(logit_scale) * cos(image features, text features) [B,T] -- or, `similarity`, the loss's 1 - that / 100 -- as ONE launch
+    (w2e_clip_logits_fwd: the two normalisations, the scale and the product; criteria/clip_loss.py:16 + the tail of clip.model.CLIP.forward),
+    and one for the gradient to the image features.  Text features and the scale are constants here (CLIP is a frozen critic)."""
+
+    @staticmethod
+    def forward(ctx, feat, text_feat, logit_scale, similarity):
+        feat, text_feat = _c(feat), _c(text_feat.detach())
+        b, d = feat.shape
+        t = text_feat.shape[0]
+        ls = logit_scale.detach().reshape(1)
+        out = torch.empty((b, t), device=feat.device, dtype=torch.float32)
+        call("w2e_clip_logits_fwd", ptr(feat), ptr(text_feat), ptr(ls), ptr(out), b, t, d, int(similarity), stream_ptr())
+        ctx.save_for_backward(feat, text_feat, ls)
+        ctx.similarity = bool(similarity)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        feat, text_feat, ls = ctx.saved_tensors
+        b, d = feat.shape
+        gf = torch.empty_like(feat)
+        call("w2e_clip_logits_bwd", ptr(_c(gout)), ptr(feat), ptr(text_feat), ptr(ls), ptr(gf), b, text_feat.shape[0], d,
+             int(ctx.similarity), stream_ptr())
+        return gf, None, None, None
+
+
+def clip_logits(feat, text_feat, logit_scale, similarity=False):
+    return _ClipLogits.apply(feat, text_feat, logit_scale, similarity)
+
+
+def clip_logits_ok(feat, text_feat, logit_scale):
+    """The fused tail applies when only the image features carry a gradient (the path's case) and everything is fp32 on the GPU."""
+    return (feat.is_cuda and feat.dtype == torch.float32 and feat.ndim == 2 and text_feat.ndim == 2 and not text_feat.requires_grad
+            and not logit_scale.requires_grad)
+
+
+class _StepLoss(torch.autograd.Function):
+    """[loss, loss_clip, loss_l2] = [clip_lambda * mean(sim) + l2_lambda * MSE(w_hat, w), mean(sim), MSE(w_hat, w)] in one launch, their
+    gradients to sim and w_hat in one (mapper/training/coach.py:223-245 without the id term).  The two loss terms are returned for the
+    log only: their gradient is not propagated (the reference detaches what it logs)."""
+
+    @staticmethod
+    def forward(ctx, sim, w_hat, w, clip_lambda, l2_lambda):
+        sim, w_hat, w = _c(sim), _c(w_hat), _c(w.detach())
+        out = torch.empty(3, device=w_hat.device, dtype=torch.float32)
+        call("w2e_step_loss_fwd", ptr(sim), sim.numel(), ptr(w_hat), ptr(w), w_hat.numel(), float(clip_lambda), float(l2_lambda),
+             ptr(out), stream_ptr())
+        ctx.save_for_backward(w_hat, w)
+        ctx.cfg = (tuple(sim.shape), float(clip_lambda), float(l2_lambda))
+        loss, l_clip, l_l2 = out[0], out[1], out[2]  # (three 0-dim outputs: no select node -- and no zero-filled select gradient -- on the tape)
+        ctx.mark_non_differentiable(l_clip, l_l2)
+        ctx.set_materialize_grads(False)
+        return loss, l_clip, l_l2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, _g1=None, _g2=None):
+        if gout is None:
+            return None, None, None, None, None
+        w_hat, w = ctx.saved_tensors
+        sim_shape, cl, l2 = ctx.cfg
+        g0 = _c(gout).reshape(1)
+        n_sim = 1
+        for v in sim_shape:
+            n_sim *= v
+        g_sim = torch.empty(sim_shape, device=w_hat.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        g_what = torch.empty_like(w_hat) if ctx.needs_input_grad[1] else None
+        call("w2e_step_loss_bwd", ptr(g0), n_sim, ptr(w_hat), ptr(w), w_hat.numel(), cl, l2, ptr(g_sim), ptr(g_what), stream_ptr())
+        return g_sim, g_what, None, None, None
+
+
+def step_loss(sim, w_hat, w, clip_lambda, l2_lambda):
+    return _StepLoss.apply(sim, w_hat, w, clip_lambda, l2_lambda)
