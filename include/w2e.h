@@ -49,9 +49,6 @@ const char* w2e_last_error(void);
  *   choose between kernels / tiles that compute the same result ("tune_blur": only bit 8, keep the LDS-tile FIR kernels
  *   for wide images; its bits 1/2/4 and "tune_skip" / "tune_clock" drop loads, arithmetic or stores, or synchronise,
  *   and are compiled in ONLY by -DW2E_TUNING: the shipped library ignores them)
- *   "tune_pipe" [W2E_TUNE_PIPE] "-1" (default: the persistent pipelined conv kernel where it measures faster -- the 32-channel
- *   same-resolution layers) | "0" never | "1" wherever its shape rules allow (tests); "tune_pipe_wgs" [W2E_TUNE_PIPE_WGS]
- *   its grid size, 0 = one workgroup per CU.  Same results to rounding either way (another summation order over K).
  *   "debug_poison" [W2E_DEBUG_POISON] "1": host-side aid -- gradient rows the merged forward declares unused are
  *   filled with NaN instead of being left unwritten, so that a consumer that reads them fails loudly (tests)
  * w2e_get_option reads "conv_precision", "deterministic", "tune_cfg", "tuning_build" (1 = compiled with -DW2E_TUNING). */

@@ -236,18 +236,14 @@ def test_irse50_backbone_matches_reference_fixture():
     assert abs(float(l_same)) < 1e-5 and zero == 0
 
 
-def test_trainable_conv_weight_never_computes_on_the_cpu():
-    """A 3x3 weight that requires grad (decoder fine-tuning) routes the layer to the per-sample-weight composition on stock GPU ops
-    (announced by a warning; the weight gradients are tested against the oracle on the GPU).  Neither that path nor the frozen
-    fast path may compute on CPU tensors: both refuse them."""
-    import warnings
+def test_trainable_conv_weight_is_refused_and_nothing_computes_on_the_cpu():
+    """A 3x3 weight that requires grad (decoder fine-tuning, off this path) is refused with an error naming the fix -- there is no stock-op
+    backend behind ModulatedConv2d -- and with frozen conv weights a CPU tensor is refused by the kernels' door: no CPU path either."""
     from where2edit_amd.stylegan2 import ModulatedConv2d, StyledConv, freeze_conv_weights
     x, w = torch.randn(1, 8, 4, 4), torch.randn(1, 512)
     for m in (ModulatedConv2d(8, 8, 3, 512), StyledConv(8, 8, 3, 512)):
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            with pytest.raises(RuntimeError, match="GPU only"):
-                m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
+        with pytest.raises(RuntimeError, match="freeze_conv_weights"):
+            m(x, w) if isinstance(m, ModulatedConv2d) else m(x, w, noise=torch.zeros(1, 1, 4, 4))
         freeze_conv_weights(m)
         assert m.noise.weight.requires_grad if isinstance(m, StyledConv) else m.modulation.weight.requires_grad
         with pytest.raises(RuntimeError, match="GPU only"):  # the kernels refuse CPU tensors

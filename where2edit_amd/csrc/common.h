@@ -16,8 +16,8 @@ struct Options {
     int conv_precision;  // 0 = exact fp32 MFMA (default); 1 = bf16x3 (W2E_CONV_PRECISION=bf16x3, opt-in)
     int deterministic;   // 1 = no fp32 atomics anywhere: ordered reductions, no split-K (W2E_DETERMINISTIC=1)
     int tune_cfg, tune_cfg_splits, tune_cfg_mode;  // force a conv tile (tests / tools/layer_bench.py); -1 = off
-    int tune_upall, tune_dma, tune_fuse, tune_pipe; // -1 = the library's own choice, 0 never, 1 always
-    int tune_print, tune_blur, tune_gemm_s, tune_pipe_wgs;
+    int tune_upall, tune_dma, tune_fuse;  // -1 = the library's own choice, 0 never, 1 always
+    int tune_print, tune_blur, tune_gemm_s;
     int tune_skip, tune_clock;  // only honoured by a -DW2E_TUNING build (they skip work / synchronise)
 };
 const Options& options();

@@ -61,8 +61,6 @@ struct ConvParams {
     int in_off;          // DOWN: the input origin is shifted by in_off (-1 = a stride-2 convolution with padding 1 of an in_h x in_w image)
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
     unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
-    int n_tiles;                          // modconv_pipe_kernel: tiles of the launch, dealt round-robin to gridDim.x workgroups
-    unsigned mg_tx, mg_ty, mg_batch;      // ceil(2^32 / d): idx / d == umulhi(idx, magic) while idx * d < 2^32
 };
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3 };
@@ -981,294 +979,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The PIPELINED same-resolution kernel: a workgroup stays for all its tiles and the fixed cost of a tile -- ~770 set-up instructions,
-// the first chunk's DMA latency, the epilogue (scale, noise, bias, LeakyReLU, 64-128 stores per wave), ~37 k cycles in which the
-// workgroup's 8 waves feed the matrix pipe nothing -- moves under the NEXT tile's MFMAs.  What the issue probe (tools/issue_probe.hip)
-// showed about v_mfma_f32_32x32x2_f32 decides the form: an MFMA holds its own wave for its 64 cycles, so a wave's other instructions
-// never hide under its own MFMAs, only under its SIMD partner's (about 3 per MFMA slot); two workgroups per CU run in lock-step and
-// gain nothing (measured); so each wave carries TWO accumulator sets of 4 and the previous tile's epilogue, the next chunk's DMA
-// pieces and the next tile's address set-up are dealt out ONE PIECE PER MFMA GROUP into the current tile's K loop:
-//   chunk 0, 1:      + one epilogue item (one accumulator register of the previous tile: scale, noise, bias, lrelu, store) per group
-//   chunk C-2:       + the next tile's patch / weight offsets (in place, behind the last DMA piece that uses the old ones) and its
-//                      in_scale / out_scale / bias tables in LDS
-//   chunk C-1:       its DMA pieces are the NEXT tile's first chunk
-// Tiles: 64 channels x 512 pixels (N >= 64) or 32 x 1024 (N = 32), 4 accumulators per wave and set, 512 threads, one workgroup per
-// CU, tiles dealt round-robin (tile = workgroup + i * workgroups).  K >= 32, full tiles only (H % th == W % tw == N % TN == 0): the
-// host falls back to modconv_kernel otherwise.
-template <int EPI, int NOB, int NPB, int WO, int WP>
-__global__ __launch_bounds__(512, 2) void modconv_pipe_kernel(ConvParams p) {
-    constexpr int NT = 512, KC = 8, TN = 32 * NOB * WO, TM = 32 * NPB * WP;
-    constexpr int TW = 64, TH = TM / TW, PW = TW + 2, PH = TH + 2, PATCH = PH * PW, PLANE = (PATCH + 15) & ~15;  // tile geometry: fixed
-    constexpr int WS_FLOATS = KC * 9 * TN;
-    constexpr int WQ4 = 9 * 2 * TN, WQ = (WQ4 + NT - 1) / NT, XT = (4 * PLANE + NT - 1) / NT, XT_MIN = 4 * TM / NT;
-    constexpr int NACC = NOB * NPB, NITEM = NACC * 16, GROUPS = 9 * NACC, NPIECE = WQ + 2 * XT;
-    static_assert(NPIECE <= GROUPS && NITEM <= 2 * GROUPS, "one DMA piece and one epilogue item per MFMA group");
-    constexpr int DG = GROUPS - 8;  // epilogue items ride on the first DG groups of chunks 0, 1 (and 2): the last stores of a chunk
-                                    // then have ~4 k cycles to complete before the vmcnt(0) that opens the next one
-    static_assert(NITEM <= 3 * DG, "the previous tile's epilogue fits the first three chunks");
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, j = lane & 31;
-    const int wo = swave / WP, wpx = swave % WP;
-    const int64_t in_plane = (int64_t)p.H * p.W;
-    constexpr int plane4 = PLANE * 4, stage_floats = WS_FLOATS + 2 * plane4;
-    const int k8 = ((p.K + 7) >> 3) * 8, tab_floats = k8 + 2 * TN;
-    float* const tabs = smem + 2 * stage_floats;  // [2][k8 in_scale | TN out_scale*gain | TN bias*gain]
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int a_base = half * TN + wo * NOB * 32 + j;
-    constexpr float kGain = EPI == EPI_ACT ? 1.4142135623730951f : 1.f;
-    const float nw = (EPI == EPI_ACT && p.noise) ? p.noise_w[0] * kGain : 0.f;
-    const unsigned plane_bytes = (unsigned)(p.H * p.W) * 4u;
-
-    // lane geometry (the same for every tile: tiles are full)
-    int base[NPB], lyx[NPB];
-#pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-        const int m = (wpx * NPB + pb) * 32 + j;
-        const int ly = m / TW, lx = m % TW;
-        base[pb] = half * PLANE + ly * PW + lx;
-        lyx[pb] = ly * p.W + lx;
-    }
-    auto raw_rsrc = [](const float* ptr, unsigned bytes) __attribute__((always_inline)) {
-        const uint64_t a64 = (uint64_t)(uintptr_t)ptr;
-        i32x4 d;
-        d[0] = (int)(unsigned)a64, d[1] = (int)(unsigned)((a64 >> 32) & 0xffffu), d[2] = (int)bytes, d[3] = 0x00020000;
-        return d;
-    };
-    const i32x4 qw = raw_rsrc(p.wp, (unsigned)(((p.K + 7) >> 3) * 9 * 2 * p.N * 16));
-    const unsigned wgroup_bytes = 9u * 2u * (unsigned)p.N * 16u;
-    const unsigned cplane = (unsigned)(2 * (lane & 3)) * (unsigned)(in_plane * 4);
-
-    struct Tile {
-        int b, n0, r0, c0;
-    };
-    auto decode = [&](int tile) __attribute__((always_inline)) {
-        Tile t;
-        // (magic = ceil(2^32 / d) does not fit 32 bits for d = 1: the host passes 0 there and the quotient is the index itself)
-        int q = p.mg_tx ? (int)__umulhi((unsigned)tile, p.mg_tx) : tile;
-        const int tx = tile - q * p.tiles_x;
-        tile = q, q = p.mg_ty ? (int)__umulhi((unsigned)tile, p.mg_ty) : tile;
-        const int ty = tile - q * p.tiles_y;
-        tile = q, q = p.mg_batch ? (int)__umulhi((unsigned)tile, p.mg_batch) : tile;
-        t.b = tile - q * p.batch, t.n0 = q * TN, t.r0 = ty * TH, t.c0 = tx * TW;
-        return t;
-    };
-    unsigned xoff[XT], woff[WQ];
-    auto set_xoff = [&](const Tile& t, int s) __attribute__((always_inline)) {  // patch slot s of tile t (origin r0-1, c0-1)
-        const int idx = (tid + s * NT) >> 2;
-        const int py = idx / PW, px = idx - py * PW;
-        const int iy = t.r0 - 1 + py, ix = t.c0 - 1 + px;
-        const bool inb = idx < PATCH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        xoff[s] = inb ? (unsigned)(iy * p.W + ix) * 4u + cplane : 0xfffffff0u;
-    };
-    auto set_woff = [&](const Tile& t, int s) __attribute__((always_inline)) {
-        const int q = tid + s * NT;
-        const int o = q % TN, rh = q / TN;  // rh = tap*2 + h
-        woff[s] = q < WQ4 ? (unsigned)((rh * p.N + t.n0 + o) * 16) : 0xfffffff0u;
-    };
-    auto fill_tabs = [&](const Tile& t, int par) __attribute__((always_inline)) {
-        float* tb = tabs + par * tab_floats;
-        if (tid < k8) {
-            const int ch = 8 * (tid >> 3) + 2 * (tid & 3) + ((tid >> 2) & 1);
-            tb[tid] = ch < p.K ? (p.in_scale ? p.in_scale[(int64_t)t.b * p.K + ch] : 1.f) : 0.f;
-        }
-        if (tid < TN) {
-            tb[k8 + tid] = (p.out_scale ? p.out_scale[(int64_t)t.b * p.N + t.n0 + tid] : 1.f) * kGain;
-            tb[k8 + TN + tid] = (EPI == EPI_ACT && p.bias) ? p.bias[t.n0 + tid] * kGain : 0.f;
-        }
-    };
-    // (descriptors span the WHOLE tensors -- the host checks they are < 4 GB -- and the image goes into the scalar offset: a
-    // descriptor that changed from tile to tile would live in VGPRs)
-    const i32x4 qx = raw_rsrc(p.x, (unsigned)((int64_t)p.batch * p.K * in_plane * 4));
-    const i32x4 ry = raw_rsrc(p.y, (unsigned)((int64_t)p.batch * p.N * in_plane * 4));
-    bool dma_on = true;  // (tuning aid, bit 2: only the first chunk of the first tile is staged)
-    auto issue_piece = [&](unsigned img_off, int k0, int stage, int i) __attribute__((always_inline)) {
-        if (!dma_on) return;
-        unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * stage_floats * 4) + (unsigned)swave * 1024u));
-        asm volatile("" : "+s"(lb));  // (this wave's 64 x 16 B of the first piece; opaque: see drain_item)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (i < WQ) {
-            const int start = i * NT + swave * 64;
-            const unsigned wbase = (unsigned)(k0 >> 3) * wgroup_bytes;
-            if ((i + 1) * NT <= WQ4 || start < WQ4)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lb + (unsigned)(i * NT * 16)), "v"(woff[i]), "s"(qw), "s"(wbase) : "memory");
-        } else if (i < NPIECE) {
-            const int sh = (i - WQ) / XT, t = (i - WQ) % XT;
-            const unsigned soff = img_off + (unsigned)(k0 + sh) * (unsigned)(in_plane * 4);
-            const int start = t * NT + swave * 64;
-            // (wave base in dwords here: lb carries swave * 1024 bytes = 4x the 256 bytes a b32 piece needs: take 3/4 of it back)
-            const unsigned xb = lb - (unsigned)swave * 768u + (unsigned)((WS_FLOATS + sh * plane4) * 4) + (unsigned)(t * NT * 4);
-            if (t < XT_MIN || start < plane4)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(xb), "v"(xoff[t]), "s"(qx), "s"(soff) : "memory");
-        }
-#endif
-    };
-    auto x_img = [&](const Tile& t) __attribute__((always_inline)) { return (unsigned)t.b * (unsigned)p.K * (unsigned)(in_plane * 4); };
-
-    // the epilogue of a finished tile, one accumulator register (item) at a time
-    struct Done {
-        unsigned yoff[NPB];
-        float nz[NPB];
-        unsigned soff0;  // byte offset of the tile's first output-channel plane: (b * N + n0) planes
-        int par;
-    };
-    auto finish_tile = [&](const Tile& t, int par, Done& d) __attribute__((always_inline)) {  // what the drain needs of tile t
-        d.soff0 = (unsigned)(t.b * p.N + t.n0) * plane_bytes, d.par = par;
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-            const int pix = (t.r0 * p.W + t.c0) + lyx[pb];
-            d.yoff[pb] = (unsigned)pix * 4u + (unsigned)(4 * half) * plane_bytes;
-            d.nz[pb] = (EPI == EPI_ACT && p.noise) ? nw * p.noise[pix] : 0.f;
-        }
-    };
-    // (written so that an item needs ONE vector base and ONE scalar base, both set per chunk behind an empty asm -- the compiler
-    // otherwise hoists the 64 per-item plane offsets and table addresses out of the chunk loop and spills ~200 registers)
-    float os_c = 0.f, bs_c = 0.f;  // the (ob, r) pair's out_scale / bias, fetched with its first item (items come in order)
-    auto drain_item = [&](const f32x16 (&acc)[NOB][NPB], const Done& d, const float* tb, unsigned soff_base, unsigned pbytes, int i) __attribute__((always_inline)) {
-        if (i >= NITEM || W2E_SKIP(p, 64)) return;  // (tuning aid, bit 6: no epilogue)
-        const int pb = i % NPB, r = (i / NPB) % 16, ob = i / (NPB * 16);
-        const int cof = ob * 32 + (r & 3) + 8 * (r >> 2);  // channel of the item relative to the wave's first (+ 4 * half)
-        if (pb == 0) os_c = tb[cof], bs_c = tb[TN + cof];
-        float v = acc[ob][pb][r] * os_c;
-        if (EPI == EPI_ACT) {
-            v += bs_c + d.nz[pb];
-            v = fmaxf(v, 0.2f * v);
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the item's plane offset on the SCALAR unit, inside the statement (left to the compiler it lands on the VALU under SGPR
-        // pressure, and a VALU-written SGPR costs a readfirstlane + 5 wait states in front of every store)
-        unsigned soff;
-        if (W2E_SKIP(p, 1)) {  // (tuning aid, bit 0: the item's arithmetic without its store)
-            asm volatile("" ::"v"(v));
-            return;
-        }
-        asm volatile("s_mul_i32 %0, %4, %5\n\ts_add_u32 %0, %0, %3\n\tbuffer_store_dword %1, %2, %6, %0 offen"
-                     : "=&s"(soff)
-                     : "v"(v), "v"(d.yoff[pb]), "s"(soff_base), "s"(pbytes), "n"(cof), "s"(ry)
-                     : "memory", "scc");
-#endif
-    };
-
-    const int n_wgs = (int)gridDim.x;
-    const int count = (p.n_tiles - (int)blockIdx.x + n_wgs - 1) / n_wgs;
-    const int chunks = p.K >> 3;
-    Tile cur = decode((int)blockIdx.x), nxt = cur;
-    unsigned qx_cur = x_img(cur), qx_nxt = qx_cur;
-#pragma unroll
-    for (int s = 0; s < XT; ++s) set_xoff(cur, s);
-#pragma unroll
-    for (int s = 0; s < WQ; ++s) set_woff(cur, s);
-    fill_tabs(cur, 0);
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) issue_piece(qx_cur, 0, 0, i);
-    int stage = 0;
-    Done done;
-    f32x16 accA[NOB][NPB], accB[NOB][NPB];
-    if (W2E_SKIP(p, 4)) dma_on = false;
-
-    // one tile: accC accumulates it, accP holds the previous tile (drained during chunks 0 and 1)
-    auto tile_body = [&](f32x16 (&accC)[NOB][NPB], const f32x16 (&accP)[NOB][NPB], int it) __attribute__((always_inline)) {
-        const bool has_prev = it > 0, has_next = it + 1 < count;
-        const int par = it & 1;
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accC[ob][pb][r] = 0.f;
-        if (has_next) nxt = decode((int)blockIdx.x + (it + 1) * n_wgs);
-        const float4* st = reinterpret_cast<const float4*>(tabs + par * tab_floats);
-        // per-tile bases of the epilogue items (opaque to loop-invariant code motion: see drain_item)
-        unsigned pbytes = (unsigned)__builtin_amdgcn_readfirstlane((int)plane_bytes);
-        unsigned soff_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(done.soff0 + (unsigned)(wo * NOB * 32) * plane_bytes));
-        const float* tb = tabs + done.par * tab_floats + k8 + 4 * half + wo * NOB * 32;
-        asm volatile("" : "+s"(pbytes), "+s"(soff_base), "+v"(tb));
-        // One chunk: wait for its DMA pieces (`tail` = epilogue stores this wave issued behind the previous chunk's last piece may still
-        // fly), barrier, MFMAs with `piece(g)` after every accumulator group.  The chunk flavours follow each other as straight-line
-        // code (a switch on the chunk index inside one loop made the register allocator spill 150-250 registers).
-        auto run_chunk = [&](int c, auto piece) __attribute__((always_inline)) {
-            if (!W2E_SKIP(p, 8)) {                   // (tuning aid, bit 3: no wait, no barrier)
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces of the chunk have landed (and its epilogue stores) ...
-                __syncthreads();                      // ... everybody's have, and everybody is done reading the other stage
-            }
-            const float4* wsc = reinterpret_cast<const float4*>(smem + stage * stage_floats);
-            const float4* xsc = wsc + WS_FLOATS / 4;
-            float4 s4[1] = {st[c * 2 + half]};
-            if (W2E_SKIP(p, 2)) {  // (tuning aid, bit 1: the pieces without the MFMAs)
-#pragma unroll
-                for (int g = 0; g < GROUPS; ++g) piece(g);
-            } else {
-                mfma_chunk<W2E_CONV_SAME, NOB, NPB, KC, TN, 0, 0, true, false>(accC, wsc, xsc, a_base, base, PW, PLANE, s4,
-                                                                             [&](int) __attribute__((always_inline)) {}, piece);
-            }
-            stage ^= 1;
-        };
-        // chunks 0, 1, 2: + the previous tile's epilogue, one item per group
-        run_chunk(0, [&](int g) __attribute__((always_inline)) {
-            if (g < NPIECE) issue_piece(qx_cur, KC, stage ^ 1, g);
-            if (has_prev && g < DG) drain_item(accP, done, tb, soff_base, pbytes, g);
-        });
-        run_chunk(1, [&](int g) __attribute__((always_inline)) {
-            if (g < NPIECE) issue_piece(qx_cur, 2 * KC, stage ^ 1, g);
-            if (has_prev && g < DG) drain_item(accP, done, tb, soff_base, pbytes, DG + g);
-        });
-        if (chunks > 4) {
-            run_chunk(2, [&](int g) __attribute__((always_inline)) {
-                if (g < NPIECE) issue_piece(qx_cur, 3 * KC, stage ^ 1, g);
-                if (has_prev && g < DG) drain_item(accP, done, tb, soff_base, pbytes, 2 * DG + g);
-            });
-            for (int c = 3; c < chunks - 2; ++c)
-                run_chunk(c, [&](int g) __attribute__((always_inline)) {
-                    if (g < NPIECE) issue_piece(qx_cur, (c + 1) * KC, stage ^ 1, g);
-                });
-        }
-        // chunk C-2: behind its last DMA piece, the next tile's offsets (in place) and tables
-        {
-            const int c = chunks - 2;
-            auto prep = [&](int g) __attribute__((always_inline)) {
-                if (g < NPIECE) issue_piece(qx_cur, (c + 1) * KC, stage ^ 1, g);
-                if (has_prev && chunks == 4 && g < DG) drain_item(accP, done, tb, soff_base, pbytes, 2 * DG + g);  // (C = 4: this IS chunk 2)
-                if (g >= NPIECE && has_next) {
-                    constexpr int SLOTS = XT + WQ, PER = (SLOTS + GROUPS - NPIECE - 1) / (GROUPS - NPIECE);
-#pragma unroll
-                    for (int q = 0; q < PER; ++q) {
-                        const int sl = (g - NPIECE) * PER + q;
-                        if (sl < XT) set_xoff(nxt, sl);
-                        else if (sl < SLOTS) set_woff(nxt, sl - XT);
-                    }
-                }
-            };
-            run_chunk(c, prep);
-            if (has_next) fill_tabs(nxt, par ^ 1), qx_nxt = x_img(nxt);
-        }
-        // chunk C-1: its pieces stage the next tile's first chunk
-        run_chunk(chunks - 1, [&](int g) __attribute__((always_inline)) {
-            if (g < NPIECE && has_next) issue_piece(qx_nxt, 0, stage ^ 1, g);
-        });
-        finish_tile(cur, par, done);
-        cur = nxt, qx_cur = qx_nxt;
-    };
-    for (int it = 0; it < count; it += 2) {
-        tile_body(accA, accB, it);
-        if (it + 1 < count) tile_body(accB, accA, it + 1);
-    }
-    // the last tile's epilogue has nobody to hide behind
-    {
-        const unsigned pbytes = (unsigned)__builtin_amdgcn_readfirstlane((int)plane_bytes);
-        const unsigned soff_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(done.soff0 + (unsigned)(wo * NOB * 32) * plane_bytes));
-        const float* tb = tabs + done.par * tab_floats + k8 + 4 * half + wo * NOB * 32;
-        if (count & 1) {
-#pragma unroll
-            for (int i = 0; i < NITEM; ++i) drain_item(accA, done, tb, soff_base, pbytes, i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NITEM; ++i) drain_item(accB, done, tb, soff_base, pbytes, i);
-        }
-    }
-}
 
 // weight [cout,cin,3,3] -> wp [ceil(K/8)][9][2][N][4]: element (kc, tap, h, n, c) = scale * W(k = 8*kc + 2*c + h, tap', n)
 // (zero where k >= K), K/N = cin/cout (transpose=0) or cout/cin (transpose=1), tap' = 8-tap when flip.
@@ -1673,60 +1383,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
         zero_async(y, sizeof(float) * (size_t)batch * n_ch * (up ? 4 * (h + 1) * W2E_PLANAR_PITCH(w) : p.out_h * p.out_w), s) != hipSuccess) {
         set_error("modconv3x3: memset failed");
         return 2;
-    }
-    // ---- the pipelined same-resolution kernel (modconv_pipe_kernel): where a tile's fixed cost is a visible share of its K loop
-    // and its assumptions hold.  Measured (tools/layer_bench.py, W2E_TUNE_PIPE=0 / -1 / 1): the 32 -> 32 @ 1024 layer -3.3 % (batch 8) /
-    // -4.3 % (batch 4); the 64 @ 512 and 128 @ 256 layers +1.5 % / +3 % (their 8-accumulator tiles amortise more per MFMA than the
-    // hidden epilogue returns) -- so: N = 32 only.  tune_pipe: -1 auto, 0 never, 1 wherever legal.
-    if (mode == W2E_CONV_SAME && !prelu && !dot_with && !use_x3 && opt.tune_cfg < 0 && !opt.deterministic && opt.tune_pipe != 0 && k_ch >= 32 && (k_ch & 7) == 0 &&
-        (n_ch == 32 || (n_ch & 63) == 0) && (opt.tune_pipe == 1 || (n_ch == 32 && k_ch <= 64)) && (int64_t)h * w >= 4096) {
-        const bool n32 = n_ch == 32;
-        const int tn = n32 ? 32 : 64, tm = n32 ? 1024 : 512;
-        const int tw = 64, th = tm / tw;
-        if (h % th == 0 && w % tw == 0 && (int64_t)batch * k_ch * h * w * 4 < ((int64_t)1 << 32) - (1 << 20) && (int64_t)batch * n_ch * h * w * 4 < ((int64_t)1 << 32) - (1 << 20)) {
-            ConvParams q = p;
-            q.tw = tw, q.th = th, q.tw_log2 = 0;
-            while ((1 << q.tw_log2) < tw) ++q.tw_log2;
-            q.tiles_x = w / tw, q.tiles_y = h / th, q.tiles_n = n_ch / tn;
-            q.ph = th + 2, q.pw = tw + 2;
-            q.plane = (q.ph * q.pw + 15) & ~15;
-            q.pw_magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)q.pw + 1);
-            q.splits = 1, q.k_per = k_ch, q.border_wgs = 0;
-            const int64_t nt64 = (int64_t)q.tiles_x * q.tiles_y * q.tiles_n * batch;
-            const auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + (unsigned)d - 1) / (unsigned)d); };
-            q.mg_tx = magic(q.tiles_x), q.mg_ty = magic(q.tiles_y), q.mg_batch = magic(batch);
-            int dmax = q.tiles_x > q.tiles_y ? q.tiles_x : q.tiles_y;
-            dmax = dmax > batch ? dmax : batch;
-            const int k8 = ((k_ch + 7) >> 3) * 8;
-            const size_t lds_p = sizeof(float) * (2 * ((size_t)72 * tn + 8 * (size_t)q.plane) + 2 * ((size_t)k8 + 2 * tn));
-            if (nt64 * dmax < ((int64_t)1 << 32) && lds_p <= 160 * 1024 && (nt64 >= 512 || opt.tune_pipe == 1)) {
-                q.n_tiles = (int)nt64;
-                const int cus = cu_count();
-                int wgs = q.n_tiles < cus ? q.n_tiles : cus;
-                if (opt.tune_pipe_wgs > 0 && opt.tune_pipe_wgs < wgs) wgs = opt.tune_pipe_wgs;  // (tests: several tiles per workgroup on small inputs)
-                if (opt.tune_print) fprintf(stderr, "  pipelined kernel: %d tiles of %dx%d px x %d ch on %d workgroups, %zu B LDS\n", q.n_tiles, th, tw, tn, wgs, lds_p);
-                static unsigned done_mask[4] = {0, 0, 0, 0};
-                if (n32) {
-                    if (act) {
-                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_ACT, 1, 4, 1, 8>, &done_mask[0]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
-                        modconv_pipe_kernel<EPI_ACT, 1, 4, 1, 8><<<wgs, 512, lds_p, s>>>(q);
-                    } else {
-                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_PLAIN, 1, 4, 1, 8>, &done_mask[1]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
-                        modconv_pipe_kernel<EPI_PLAIN, 1, 4, 1, 8><<<wgs, 512, lds_p, s>>>(q);
-                    }
-                } else {
-                    if (act) {
-                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_ACT, 2, 2, 1, 8>, &done_mask[2]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
-                        modconv_pipe_kernel<EPI_ACT, 2, 2, 1, 8><<<wgs, 512, lds_p, s>>>(q);
-                    } else {
-                        W2E_REQUIRE(big_lds_once((const void*)modconv_pipe_kernel<EPI_PLAIN, 2, 2, 1, 8>, &done_mask[3]), "modconv3x3 (pipelined): cannot enable %zu B of LDS", lds_p);
-                        modconv_pipe_kernel<EPI_PLAIN, 2, 2, 1, 8><<<wgs, 512, lds_p, s>>>(q);
-                    }
-                }
-                W2E_LAUNCH_CHECK("modconv3x3 (pipelined)");
-                return 0;
-            }
-        }
     }
     bool ok = false;
     if (use_x3 && use_all) {

@@ -51,17 +51,26 @@ def _wino_form(b, k, n, h, w):
         return 0
     if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0:
         return 0
-    # the fused kernel (no transform-domain tensor in HBM): where its shapes allow, up to 128 input channels it beats both the direct
-    # kernel and the GEMM form (64 -> 64 @ 256^2, batch 8: 191 us against 350 / 353; 128 -> 256 @ 64^2: 86 / 171 / 114)
-    if FUSED_ENCODER and K.WINOGRAD in ("auto", K.FUSED) and K._fused_shape_ok(b, k, n, h, w) \
-            and (K.WINOGRAD == K.FUSED or (k <= 128 and 18.0 * b * k * n * h * w >= 3e9)):
-        return K.FUSED
+    # Measured per shape (profiles/r04_irse_shapes.txt; batch 8 of the e4e encoder / batch 16 of the id-loss network, us, direct / GEMM
+    # form / fused): 64 -> 64 @ 256^2 302 / 254 / 167; 64 -> 64 @ 128^2 81 / 49 / 45; 64 -> 128 @ 128^2 147 / 72 / 86; 128 -> 128 @ 64^2
+    # 80 / 53 / 41; 128 -> 256 @ 64^2 150 / 57 / 77; 256 -> 256 @ 32^2 88 / 45 / 70; 64 -> 64 @ 112^2 (batch 16) 162 / 87 / -;
+    # 64 -> 128 @ 56^2 87 / 42; 128 -> 256 @ 28^2 80 / 55; below ~3 GFLOP of direct work per call the direct kernel wins (64 -> 64 @ 56^2,
+    # batch 8: 26 / 39).  The fused kernel repeats its input transform per 32 output channels, the GEMM form pays one pass over V:
+    # fused where the layer does not widen (N <= K <= 128), the GEMM form otherwise.
+    work_ok = 18.0 * b * k * n * h * w >= 3e9
+    fused_ok = FUSED_ENCODER and K._fused_shape_ok(b, k, n, h, w)
+    gemm_ok = K._gemm_shape_ok(b, k, n, h, w, dot=False)
     if K.WINOGRAD == K.FUSED:
+        return K.FUSED if fused_ok else 0
+    if K.WINOGRAD == 4:
+        return 4 if gemm_ok else 0
+    if not work_ok:
         return 0
-    # measured: the form wins from 128 channels on one side and ~3 GFLOP of direct work per call
-    if K.WINOGRAD == "auto" and not (k >= 64 and max(k, n) >= 128 and 18.0 * b * k * n * h * w >= 3e9):
-        return 0
-    return 4 if K._gemm_shape_ok(b, k, n, h, w, dot=False) else 0
+    if fused_ok and k <= 128 and n <= k:
+        return K.FUSED
+    if gemm_ok and k >= 64:
+        return 4
+    return K.FUSED if (fused_ok and k <= 128) else 0
 
 
 def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out_scale=None, bias=None, slope=None, out=None, form=None):

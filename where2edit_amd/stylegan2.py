@@ -36,48 +36,18 @@ def invalidate_caches(module):
             m._text_cache = None
 
 
-_WARNED_TRAINABLE = False
-
-
 def _trainable_weight(mod):
-    """True when autograd expects a gradient for this conv weight.  The packed-weight kernels (K1) compute none -- the path this
-    package accelerates never optimises the decoder (coach.py:174-180) -- so such a layer runs `_modconv_trainable` below, the
-    reference's own composition on stock PyTorch-ROCm ops, announced once."""
-    global _WARNED_TRAINABLE
-    if not (torch.is_grad_enabled() and mod.weight.requires_grad):
-        return False
-    if not _WARNED_TRAINABLE:
-        import warnings
-        warnings.warn("where2edit_amd: a ModulatedConv2d weight requires grad (decoder fine-tuning): that layer runs as the "
-                      "reference's per-sample-weight grouped convolution on stock PyTorch-ROCm ops (MIOpen), not on the HIP "
-                      "kernels.  Call decoder.requires_grad_(False) / stylegan2.freeze_conv_weights() for the fast path.")
-        _WARNED_TRAINABLE = True
-    return True
-
-
-def _modconv_trainable(mod, input, style):
-    """model.py:239-276 for a weight that is being trained: per-sample weights, one grouped (transposed) convolution, autograd
-    through everything.  `style` is the post-affine [B,1,Cin,1,1] tensor.  The FIR of the up/down-sampling branches is the HIP
-    upfirdn2d op (differentiable in its input)."""
-    if not input.is_cuda:
-        raise RuntimeError("where2edit_amd ops run on the GPU only (got a CPU tensor); the CPU restatement is oracle/, for tests")
-    batch, cin, height, width = input.shape
-    cout, k = mod.out_channel, mod.kernel_size
-    weight = mod.scale * mod.weight * style
-    if mod.demodulate:
-        weight = weight * torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + mod.eps).view(batch, cout, 1, 1, 1)
-    x = input.reshape(1, batch * cin, height, width)
-    if mod.upsample:
-        wt = weight.transpose(1, 2).reshape(batch * cin, cout, k, k)
-        out = F.conv_transpose2d(x, wt, padding=0, stride=2, groups=batch)
-        return mod.blur(out.view(batch, cout, out.shape[2], out.shape[3]))
-    if mod.downsample:
-        x = mod.blur(input)
-        out = F.conv2d(x.reshape(1, batch * cin, x.shape[2], x.shape[3]), weight.view(batch * cout, cin, k, k), padding=0, stride=2,
-                       groups=batch)
-        return out.view(batch, cout, out.shape[2], out.shape[3])
-    out = F.conv2d(x, weight.view(batch * cout, cin, k, k), padding=mod.padding, groups=batch)
-    return out.view(batch, cout, out.shape[2], out.shape[3])
+    """Refuses a conv weight that autograd expects a gradient for.  The packed-weight kernels (K1) compute none: the path this package
+    accelerates never optimises the decoder (mapper/training/coach.py:174-180 hands only net.mapper's parameters to the optimizer), and a
+    second, stock-op backend inside ModulatedConv2d for that case (rounds 2-3 ran the reference's per-sample-weight grouped convolution on
+    MIOpen here) is exactly the silent fallback this package does not have.  One kernel path, or an error that says what to do."""
+    if torch.is_grad_enabled() and mod.weight.requires_grad:
+        raise RuntimeError(
+            "where2edit_amd: a ModulatedConv2d weight requires grad (decoder fine-tuning).  The HIP kernels treat the decoder as frozen -- "
+            "as the path they serve does (coach.py:174-180 optimises net.mapper only) -- and produce no conv-weight gradient; there is no "
+            "stock-op fallback.  Call stylegan2.freeze_conv_weights(decoder) (or decoder.requires_grad_(False)); gradients to latents, "
+            "styles, noise strengths and biases are unaffected.")
+    return False
 
 
 def freeze_conv_weights(module):
