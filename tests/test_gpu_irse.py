@@ -215,7 +215,7 @@ def test_config5_invert_and_edit_pipeline_matches_oracle(bsz):
         w_o = OE.encoder4editing(esd, img)
         _, _, codes_o = OG.generator_forward(gsd, [w_o], size=size, input_is_latent=True, randomize_noise=False, return_latents=True)
         img_o, _, _, feats_o = OG.generator_forward(gsd, [codes_o], size=size, input_is_stylespace=True, randomize_noise=False, return_features=True)
-        feats_o = list(feats_o) + [gsd["input.input"]]
+        feats_o = list(feats_o) + [gsd["input.input"].repeat(bsz, 1, 1, 1)]  # (run_attention.py:1110 appends the constant input, per sample)
         # centres = 20 pixels of the layer-13 activation (+ their positions): a non-trivial, well-separated assignment
         f13 = feats_o[att - 1]
         idx = torch.randperm(64 * 64, generator=torch.Generator().manual_seed(3))[:k]

@@ -336,7 +336,7 @@ GEMM_SPLITS = 0  # > 0: force w2e_wino_gemm's K split (tests); 0: the library's 
 
 
 def wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n, h, w, act_code=0, noise=None, noise_w=None, bias=None, slope=None,
-                   dot_with=None, dot=None):
+                   dot_with=None, dot=None, tag="modconv mode 0"):
     """One same-resolution 3x3 conv in the F(4x4,3x3) GEMM form (K1g): w2e_wino_pack_input -> w2e_wino_gemm; `dot` [b,n] is accumulated
     into (in a fixed order, no atomics) when dot_with is given."""
     b = x.shape[0]
@@ -350,7 +350,7 @@ def wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n, h, w, act_code=0, noise=
         splits = -(-(k // 8) // kcs)
         ws_floats = b * n * max(1, (h // 4) * (w // 4) // 32) + (splits * b * n * h * w if splits > 1 else 0)
     if WINO_LOG is not None:
-        WINO_LOG.append(f"modconv mode 0 (winograd F(4x4,3x3) gemm{', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
+        WINO_LOG.append(f"{tag} (winograd F(4x4,3x3) gemm{', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
                         f"36 x [{n}x{k}] x [{k}x{tp.value}], {splits} K split(s)")
     vf = torch.empty(36 * k * tp.value, device=x.device, dtype=torch.float32)
     work = torch.empty(ws_floats, device=x.device, dtype=torch.float32) if (splits > 1 or dot_with is not None) else None

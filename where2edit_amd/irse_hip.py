@@ -91,7 +91,7 @@ def conv3x3(x, wp, n_out, h, w, mode=K.MODE_SAME, down_pad=0, in_scale=None, out
                 call("w2e_wino_fused", ptr(x), ptr(in_scale), ptr(K._wino_weights_fused(wp, k, n_out)), ptr(out_scale), ptr(y), b, k, n_out, h, w,
                      epi, None, None, ptr(bias), ptr(slope), None, None, K.FUSED_WGS, stream_ptr())
             else:
-                K.wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n_out, h, w, epi, None, None, bias, slope)
+                K.wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n_out, h, w, epi, None, None, bias, slope, tag="conv3x3")
             return y
     if out is not None:
         assert mode != K.MODE_UP and out.shape == (b, n_out, h, w) and out.is_contiguous()
