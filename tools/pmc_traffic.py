@@ -20,10 +20,8 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        if "modconv_kernel" in name or "modconv_pipe_kernel" in name:
+        if "modconv_kernel" in name:
             key = "w2e::modconv_kernel<*>"
-        elif name.startswith("Cijk_"):
-            key = "Cijk_* (library fp32 GEMMs: the Winograd-domain contraction; a few small stock-op GEMMs)"
         else:
             key = name.split("(")[0][:60]
         d[key][0] += 1
@@ -41,10 +39,10 @@ def main():
              "# uncalibrated: its corrected figure is an upper bound, the uncorrected one a lower bound.",
              "# kernel, launches, FETCH_SIZE KB/launch, WRITE_SIZE KB/launch, HBM MB/launch corrected, uncorrected"]
     out = {}
-    # every 3x3 modulated conv call of the step = a direct launch, or a Winograd-form call (one wino*_output launch each, with its
-    # input transform and its GEMM): the `traffic` of bench.py's roofline is their HBM bytes per call
-    conv = [k for k in f if k in w and ("modconv_kernel" in k or "wino" in k or k.startswith("Cijk_"))]
-    calls = sum(f[k][0] for k in conv if "modconv_kernel" in k or "_output_kernel" in k or "wino4_fused" in k)
+    # every 3x3 modulated conv call of the step = a direct launch, or a Winograd-form call (one wino4_fused3 launch, or one wino4_gemm
+    # launch with its packed input transform and finish launch): the `traffic` of bench.py's roofline is their HBM bytes per call
+    conv = [k for k in f if k in w and ("modconv_kernel" in k or "wino" in k)]
+    calls = sum(f[k][0] for k in conv if "modconv_kernel" in k or "wino4_gemm_kernel" in k or "wino4_fused" in k)
     if calls:
         ft, wt = sum(f[k][1] for k in conv) / calls, sum(w[k][1] for k in conv) / calls
         lines.append(f"all 3x3 modulated conv calls (direct launches + Winograd-form calls), {calls}, {ft:.0f}, {wt:.0f}, {(2 * ft + wt) / 1024:.1f}, {(ft + wt) / 1024:.1f}")

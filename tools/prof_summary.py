@@ -14,16 +14,19 @@ print(f"# {path}\n# total kernel time {tot / steps / 1e6:.3f} ms/step over {step
 fam = {}
 for r in rows:
     name = r["Name"]
-    key = ("w2e::modconv_kernel<*>" if ("modconv_kernel" in name or "modconv_pipe_kernel" in name)
-           else "Cijk_* (library fp32 GEMMs)" if name.startswith("Cijk_") else name.split("(")[0][:70])
+    key = ("w2e::modconv_kernel<*>" if "modconv_kernel" in name
+           else "Cijk_* (library fp32 GEMMs: stock-op mm of the [B,512]-sized tails)" if name.startswith("Cijk_") else name.split("(")[0][:70])
     c, t = fam.get(key, (0, 0))
     fam[key] = (c + int(r["Calls"]), t + int(r["TotalDurationNs"]))
-# the 3x3 modulated convs as bench.py's roofline counts them: direct launches + Winograd-form calls (input transform + the
-# library's strided-batched GEMM + output transform; the Cijk_* rows also hold a few small stock-op GEMMs, < 0.06 ms per step)
-conv_t = sum(int(r["TotalDurationNs"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"]
-             or "wino" in r["Name"] or r["Name"].startswith("Cijk_"))
-conv_c = sum(int(r["Calls"]) for r in rows if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"] or "_output_kernel" in r["Name"] or "wino4_fused" in r["Name"])
-wino_t = sum(int(r["TotalDurationNs"]) for r in rows if "wino" in r["Name"] or r["Name"].startswith("Cijk_"))
+# the 3x3 modulated convs as bench.py's roofline counts them: direct launches + Winograd-form calls (one wino4_fused3 launch, or one
+# wino4_gemm launch with its packed input transform and, for a split K, its finish launch -- all kernels of this repo)
+def is_conv(n):
+    return "modconv_kernel" in n or "wino" in n
+
+
+conv_t = sum(int(r["TotalDurationNs"]) for r in rows if is_conv(r["Name"]))
+conv_c = sum(int(r["Calls"]) for r in rows if "modconv_kernel" in r["Name"] or "wino4_gemm_kernel" in r["Name"] or "wino4_fused" in r["Name"])
+wino_t = sum(int(r["TotalDurationNs"]) for r in rows if "wino" in r["Name"])
 if conv_c:
     print(f"# all 3x3 modulated conv calls: {conv_t / steps / 1e6:.3f} ms/step, {conv_c / steps:.1f} calls/step, {conv_t / conv_c / 1e3:.1f} us per call "
           f"(of which Winograd-form calls: {wino_t / steps / 1e6:.3f} ms/step)")
@@ -33,5 +36,5 @@ for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t / steps / 1e6:9.3f} {c / steps:8.1f} {t / c / 1e3:10.1f} {100.0 * t / tot:6.2f}%  {k}")
 print("# modconv instantiations <MODE,EPI,NOB,NPB,WO,WP,KC>")
 for r in rows:
-    if "modconv_kernel" in r["Name"] or "modconv_pipe_kernel" in r["Name"]:
+    if "modconv_kernel" in r["Name"]:
         print(f"{int(r['TotalDurationNs']) / steps / 1e6:9.3f} {int(r['Calls']) / steps:8.1f} {float(r['AverageNs']) / 1e3:10.1f}  {r['Name'][5:60]}")
