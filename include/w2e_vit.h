@@ -47,38 +47,43 @@ int w2e_attn_fwd(const float* qkv, float* out, int batch, int seq, int heads, vo
 /* gqkv [B,L,3,heads,64] from gout [B,L,heads*64]; probabilities are recomputed from qkv. */
 int w2e_attn_bwd(const float* qkv, const float* gout, float* gqkv, int batch, int seq, int heads, void* stream);
 
-/* ---- second generation, shaped for M = 50*batch rows (csrc/vit2.hip) ----------------------------------------------------
- * w2e_gemm_fm:  C[M,N] = A[M,K] x B[N,K]^T  (both operands row-major with K contiguous: nn.Linear's weight for the forward,
- * its cached transpose for the input gradient).  One workgroup holds ALL rows of a 224-row M tile (7 waves x 32 rows) and 32
- * columns; K is split over `splits` slices.  epi:
- *   0 PLAIN      c = acc + bias                                   (splits = 1)
- *   1 PARTIAL    c[z] = acc of K-slice z, one [M, ldc] slab per slice (slab stride M*ldc), no bias: the CONSUMER sums the
- *                slabs (w2e_reduce_ln_fwd, w2e_layernorm_bwd_part, w2e_attn2_*) -- no atomics, no memset, deterministic
- *   2 GELU_DUAL  c = acc + bias, c2 = QuickGELU(c)                (c_fc: the pre-activation is kept for the backward)
- *   3 GELU_GRAD  c = acc * QuickGELU'(aux)                        (input gradient through c_proj and the activation)
- * K % 32 == 0, lda/ldb % 4 == 0, 16-byte aligned operands.  w2e_gemm_fm_splits suggests `splits` for a shape. */
-int w2e_gemm_fm_splits(int m, int n, int k, int allow_split);
-int w2e_gemm_fm(const float* a, const float* b, float* c, float* c2, int m, int n, int k, int lda, int ldb, int ldc, int splits,
-                int epi, const float* bias, const float* aux, void* stream);
-/* Sum of split-K slabs [rows, n] fused with the QuickGELU pair of the MLP:
+/* ---- the tower at M = 50*batch rows (csrc/vit2.hip: the kernels around the GEMMs; csrc/vit3.hip: the GEMM) ------------------------
+ * Split-K partials of a GEMM are WRITTEN as slabs [rows, n], `slab` elements apart, and summed in ascending order by the kernel that
+ * consumes them (no atomics, no memset, bit-reproducible); each producer can write the tensor the NEXT GEMM consumes in that GEMM's
+ * operand packing (`*_packed_rows`).
+ * Sum of split-K slabs [rows, n] fused with the QuickGELU pair of the MLP:
  *   mode 0:  h = sum + bias[n],  g = QuickGELU(h)      (after c_fc)
- *   mode 1:  h = sum * QuickGELU'(aux)                 (input gradient through the activation; g unused) */
+ *   mode 1:  h = sum * QuickGELU'(aux)                 (input gradient through the activation; g unused)
+ * packed_rows > 0: the tensor the next GEMM consumes (g in mode 0, h in mode 1) is written K-quad-major with that many padded rows
+ * (w2e_gemm_pk's A operand: P[q][row] = X[row][4q .. 4q+3]); mode 0's h stays row-major (kept for the backward). */
 int w2e_reduce_gelu(const float* part, int nsplit, int64_t slab, const float* bias, const float* aux, float* h, float* g,
-                    int64_t rows, int n, int mode, void* stream);
+                    int64_t rows, int n, int mode, int packed_rows, void* stream);
 /* x = sum_{s<nsplit} part[s] (+ bias[dim]) (+ residual) -> x_out (may be NULL);  y = LayerNorm(x)*gamma + beta with mean / rstd
  * saved (y may be NULL: reduction only).  part: nsplit slabs of [rows, dim], `slab` elements apart.  dim in {512, 768, 1024}. */
 int w2e_reduce_ln_fwd(const float* part, int nsplit, int64_t slab, const float* bias, const float* residual, float* x_out,
                       const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int dim, float eps,
-                      void* stream);
-/* gx = LN'(sum_s gpart[s]) + add   (add may be NULL). */
+                      int y_packed_rows, void* stream);   /* y_packed_rows > 0: y written K-quad-major (w2e_gemm_pk's A operand) */
+/* gx = LN'(sum_s gpart[s]) + add   (add may be NULL); gx_packed != NULL: a second copy of gx, K-quad-major with packed_rows padded rows. */
 int w2e_layernorm_bwd_part(const float* gpart, int nsplit, int64_t slab, const float* x, const float* gamma, const float* mean,
-                           const float* rstd, const float* add, float* gx, int64_t rows, int dim, void* stream);
+                           const float* rstd, const float* add, float* gx, int64_t rows, int dim, float* gx_packed, int packed_rows,
+                           void* stream);
 /* The attention core on MFMA.  qkv = sum of nsplit slabs [B*L, 3*heads*64] (+ bias[3*heads*64]); out [B*L, heads*64].
  * Backward: gout = sum of gsplit slabs [B*L, heads*64]; gqkv [B*L, 3*heads*64] (probabilities recomputed). */
 int w2e_attn2_fwd(const float* qkv, int nsplit, int64_t slab, const float* bias, float* out, int batch, int seq, int heads,
-                  void* stream);
+                  int out_packed_rows, void* stream);     /* *_packed_rows > 0: out / gqkv written K-quad-major (w2e_gemm_pk's A operand) */
 int w2e_attn2_bwd(const float* qkv, int nsplit, int64_t slab, const float* bias, const float* gout, int gsplit, int64_t gslab,
-                  float* gqkv, int batch, int seq, int heads, void* stream);
+                  float* gqkv, int batch, int seq, int heads, int g_packed_rows, void* stream);
+
+/* ---- third-generation tower GEMM (csrc/vit3.hip): both operands pre-packed K-quad-major, P[q][r] (one float4) = X[r][4q .. 4q+3] --
+ * the word a lane feeds to four consecutive v_mfma_f32_32x32x2_f32 -- so that they go global/L2 -> registers with no LDS and no barrier:
+ * one independent wave per (32 rows x 64 columns x K slice).  w2e_pack_kq packs X [rows, K] (row stride ldx; rows up to rows_padded are
+ * zero-filled) or, transposed != 0, X^T of X [K, rows].  w2e_gemm_pk: C[z] = A x B^T over K slice z, written as `splits` slabs
+ * [m, ldc] (their consumers -- w2e_reduce_ln_fwd, w2e_layernorm_bwd_part, w2e_reduce_gelu, w2e_attn2_* -- sum them in ascending order).  K %% 8 == 0; m_padded %% 32 == 0, n_padded %% 64 == 0. */
+int w2e_pack_kq(const float* x, float* packed, int rows, int rows_padded, int k, int ldx, int transposed, void* stream);
+int w2e_gemm_pk(const float* a_packed, const float* b_packed, float* c, int m, int n, int k, int m_padded, int n_padded, int ldc,
+                int splits, void* stream);
+/* The K split w2e_gemm_pk wants for a shape: about one wave per SIMD (tiles x splits ~ 4 x CUs), every slice >= 4 chunks of 8. */
+int w2e_gemm_pk_splits(int m, int n, int k);
 
 /* ---- the scalar tail of a mapper step (csrc/losstail.hip): ~37 [B,T]- / [B,18,512]-sized stock launches as four -------------------
  * criteria/clip_loss.py:16 + the tail of OpenAI clip.model.CLIP.forward: out[b,t] = exp(*logit_scale) * <f_b, t_t> / (|f_b| |t_t|)

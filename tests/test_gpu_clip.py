@@ -121,34 +121,7 @@ def test_clip_loss_1024_vs_oracle():
     assert loss(ig, tokens.to(DEV)) is not None and m._text_cache is not None
 
 
-# ---------------------------------------------------------------------------------------------- second-generation kernels
-@pytest.mark.parametrize("m,n,k", [(200, 2304, 768), (200, 768, 3072), (400, 3072, 768), (200, 768, 768), (37, 40, 64), (230, 96, 160), (4, 512, 768)])
-def test_gemm_fm_vs_torch(m, n, k):
-    """w2e_gemm_fm (whole-M workgroups, LDS-DMA ring, split-K slabs) in every epilogue, incl. two M tiles (m > 224),
-    ragged N and M, and every split count that divides K into 32-deep steps."""
-    from where2edit_amd import vit_hip as V
-    g = torch.Generator().manual_seed(m + n + k)
-    a = torch.randn(m, k, generator=g).to(DEV)
-    w = torch.randn(n, k, generator=g).to(DEV)
-    bias = torch.randn(n, generator=g).to(DEV)
-    ref = a.double() @ w.double().t()
-    tol = 2e-6 * (k ** 0.5)
-    assert_close(V._gemm_fm(a, w, V.EPI_PLAIN, bias=bias), ref + bias.double(), tol, "plain")
-    steps = k // 32
-    for sp in (1, 2, 3, 6, V._fm_splits(m, n, k)):
-        if sp > steps or -(-steps // (-(-steps // sp))) != sp:
-            continue
-        slabs = V._gemm_fm(a, w, V.EPI_PARTIAL, splits=sp)
-        assert slabs.shape == (sp, m, n)
-        assert_close(slabs.double().sum(0), ref, tol, f"partial x{sp}")
-    c, c2 = V._gemm_fm(a, w, V.EPI_GELU_DUAL, bias=bias)
-    h = ref + bias.double()
-    assert_close(c, h, tol, "gelu-dual c"), assert_close(c2, h * torch.sigmoid(1.702 * h), tol, "gelu-dual gelu(c)")
-    aux = torch.randn(m, n, generator=g).to(DEV)
-    s = torch.sigmoid(1.702 * aux.double())
-    assert_close(V._gemm_fm(a, w, V.EPI_GELU_GRAD, aux=aux), ref * (s * (1 + 1.702 * aux.double() * (1 - s))), 1e-5, "gelu-grad")
-
-
+# ---------------------------------------------------------------------------------------------- the M = 50*batch kernels
 def test_reduce_ln_and_attention_v2_vs_torch():
     from where2edit_amd import vit_hip as V
     from where2edit_amd._lib import call, ptr, stream_ptr
@@ -176,12 +149,12 @@ def test_reduce_ln_and_attention_v2_vs_torch():
         q, k, v = qkv.view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
         ref = ((q @ k.transpose(-1, -2) / 8).softmax(-1) @ v).transpose(1, 2).reshape(B * L, H * 64)
         out = torch.empty(B * L, H * 64, device=DEV)
-        call("w2e_attn2_fwd", ptr(slabs), S, B * L * d3, ptr(bias), ptr(out), B, L, H, stream_ptr())
+        call("w2e_attn2_fwd", ptr(slabs), S, B * L * d3, ptr(bias), ptr(out), B, L, H, 0, stream_ptr())
         assert_close(out, ref, 1e-5, f"attn2 L={L}")
         gs = torch.randn(2, B * L, H * 64, generator=g).to(DEV)
         (gref,) = torch.autograd.grad(ref, qkv, gs.double().sum(0))
         gq = torch.empty(B * L, d3, device=DEV)
-        call("w2e_attn2_bwd", ptr(slabs), S, B * L * d3, ptr(bias), ptr(gs), 2, B * L * H * 64, ptr(gq), B, L, H, stream_ptr())
+        call("w2e_attn2_bwd", ptr(slabs), S, B * L * d3, ptr(bias), ptr(gs), 2, B * L * H * 64, ptr(gq), B, L, H, 0, stream_ptr())
         assert_close(gq, gref.reshape(B * L, d3), 2e-5, f"attn2 grad L={L}")
 
 
@@ -211,19 +184,57 @@ def test_vit_b32_tower_v2_matches_first_generation_and_oracle_gradient(monkeypat
             assert_close(f2, fo, 1e-3, "features vs oracle"), assert_close(g2, go, 2e-3, "image gradient vs oracle")
 
 
-def test_mlp_up_split_paths_vs_torch():
-    """c_fc and its input gradient in the split-K + w2e_reduce_gelu form (what M = 200 takes at N = 3072) and unsplit."""
+def _unpack(p, m):
+    """[K/4, mpad, 4] K-quad-major -> [m, K] row-major."""
+    return p[:, :m].permute(1, 0, 2).reshape(m, -1)
+
+
+def test_reduce_gelu_and_the_packed_outputs_of_the_tower_kernels():
+    """w2e_reduce_gelu (the QuickGELU pair / its derivative on a sum of split-K slabs) against float64, and every producer's
+    `packed_rows` form -- w2e_reduce_ln_fwd, w2e_layernorm_bwd_part, w2e_reduce_gelu (both modes), w2e_attn2_fwd / _bwd -- against its own
+    row-major output: the K-quad-major tensor (w2e_gemm_pk's A operand) must hold the same values, bit for bit."""
     from where2edit_amd import vit_hip as V
+    from where2edit_amd._lib import call, ptr, stream_ptr
     g = torch.Generator().manual_seed(9)
     for m in (200, 8):
-        y, w, b = torch.randn(m, 768, generator=g).to(DEV), torch.randn(3072, 768, generator=g).to(DEV) * 0.05, torch.randn(3072, generator=g).to(DEV)
-        h, act = V._mlp_up(y, w, b)
-        href = y.double() @ w.double().t() + b.double()
-        assert_close(h, href, 1e-5, "h"), assert_close(act, href * torch.sigmoid(1.702 * href), 1e-5, "QuickGELU(h)")
-        gy = torch.randn(m, 768, generator=g).to(DEV)
-        wt = torch.randn(3072, 768, generator=g).to(DEV) * 0.05
-        s = torch.sigmoid(1.702 * href)
-        assert_close(V._mlp_up_grad(gy, wt, h), (gy.double() @ wt.double().t()) * (s * (1 + 1.702 * href * (1 - s))), 1e-5, "gelu-grad")
+        mpad, n = -(-m // 32) * 32, 3072
+        part = torch.randn(3, m, n, generator=g).to(DEV)
+        bias, aux = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+        h, act = torch.empty(m, n, device=DEV), torch.empty(m, n, device=DEV)
+        call("w2e_reduce_gelu", ptr(part), 3, m * n, ptr(bias), None, ptr(h), ptr(act), m, n, 0, 0, stream_ptr())
+        href = part.double().sum(0) + bias.double()
+        assert_close(h, href, 1e-6, "h"), assert_close(act, href * torch.sigmoid(1.702 * href), 1e-5, "QuickGELU(h)")
+        h2, actp = torch.empty(m, n, device=DEV), torch.empty(n // 4, mpad, 4, device=DEV)
+        call("w2e_reduce_gelu", ptr(part), 3, m * n, ptr(bias), None, ptr(h2), ptr(actp), m, n, 0, mpad, stream_ptr())
+        assert torch.equal(h2, h) and torch.equal(_unpack(actp, m), act), "mode 0 packed"
+        out = torch.empty(m, n, device=DEV)
+        call("w2e_reduce_gelu", ptr(part), 3, m * n, None, ptr(aux), ptr(out), None, m, n, 1, 0, stream_ptr())
+        s_ = torch.sigmoid(1.702 * aux.double())
+        assert_close(out, part.double().sum(0) * (s_ * (1 + 1.702 * aux.double() * (1 - s_))), 1e-5, "gelu-grad")
+        outp = torch.empty(n // 4, mpad, 4, device=DEV)
+        call("w2e_reduce_gelu", ptr(part), 3, m * n, None, ptr(aux), ptr(outp), None, m, n, 1, mpad, stream_ptr())
+        assert torch.equal(_unpack(outp, m), out), "mode 1 packed"
+    m, dim, mpad = 150, 768, 160
+    part = torch.randn(2, m, dim, generator=g).to(DEV)
+    gamma, beta = (torch.randn(dim, generator=g) * 0.2 + 1).to(DEV), (torch.randn(dim, generator=g) * 0.2).to(DEV)
+    x, y, mean, rstd = V._reduce_ln(part, None, None, gamma, beta, 1e-5)
+    _, yp, _, _ = V._reduce_ln(part, None, None, gamma, beta, 1e-5, mpad=mpad)
+    assert yp.shape == (dim // 4, mpad, 4) and torch.equal(_unpack(yp, m), y), "LayerNorm packed"
+    gx = V._ln_bwd_part(part, x, gamma, mean, rstd, None)
+    gx2, gxp = V._ln_bwd_part(part, x, gamma, mean, rstd, None, mpad=mpad)
+    assert torch.equal(gx2, gx) and torch.equal(_unpack(gxp, m), gx), "LayerNorm backward packed"
+    B, L, H = 3, 50, 12
+    d3, mm = 3 * H * 64, 3 * 50
+    slabs, bias = torch.randn(2, mm, d3, generator=g).to(DEV), torch.randn(d3, generator=g).to(DEV)
+    o, op = torch.empty(mm, H * 64, device=DEV), torch.empty(H * 16, mpad, 4, device=DEV)
+    call("w2e_attn2_fwd", ptr(slabs), 2, mm * d3, ptr(bias), ptr(o), B, L, H, 0, stream_ptr())
+    call("w2e_attn2_fwd", ptr(slabs), 2, mm * d3, ptr(bias), ptr(op), B, L, H, mpad, stream_ptr())
+    assert torch.equal(_unpack(op, mm), o), "attention packed"
+    gs = torch.randn(1, mm, H * 64, generator=g).to(DEV)
+    gq, gqp = torch.empty(mm, d3, device=DEV), torch.empty(d3 // 4, mpad, 4, device=DEV)
+    call("w2e_attn2_bwd", ptr(slabs), 2, mm * d3, ptr(bias), ptr(gs), 1, mm * H * 64, ptr(gq), B, L, H, 0, stream_ptr())
+    call("w2e_attn2_bwd", ptr(slabs), 2, mm * d3, ptr(bias), ptr(gs), 1, mm * H * 64, ptr(gqp), B, L, H, mpad, stream_ptr())
+    assert torch.equal(_unpack(gqp, mm), gq), "attention backward packed"
 
 
 @pytest.mark.parametrize("b,t,d", [(4, 1, 512), (3, 5, 200), (8, 2, 768)])
@@ -260,3 +271,38 @@ def test_fused_loss_tail_equals_the_stock_composition(b, t, d):
     ref.backward()
     assert_close(w_hat.grad, wd.grad, 1e-5, "d loss / d w_hat")
     assert_close(feat.grad, fd.grad, 1e-5, "d loss / d features (through both fused nodes)")
+
+
+@pytest.mark.parametrize("m,n,k", [(200, 2304, 768), (200, 768, 3072), (400, 3072, 768), (50, 768, 768), (77, 200, 104)])
+def test_gemm_pk_and_its_packing_vs_float64(m, n, k):
+    """csrc/vit3.hip: w2e_pack_kq (plain and transposed) and w2e_gemm_pk (both operands K-quad-major, register-fed, one wave per tile and
+    K slice, split-K slabs) against float64: the tower's shapes at batch 4 / 8 / 1, and a ragged one (rows and columns that pad, a K whose
+    last slice is short); every admissible split count incl. the one w2e_gemm_pk_splits picks."""
+    from where2edit_amd import _lib
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    w = torch.randn(n, k, generator=g).to(DEV)
+    mpad, npad = -(-m // 32) * 32, -(-n // 64) * 64
+    ap = torch.full((k // 4, mpad, 4), float("nan"), device=DEV)
+    wp = torch.empty((k // 4, npad, 4), device=DEV)
+    call("w2e_pack_kq", ptr(a), ptr(ap), m, mpad, k, k, 0, stream_ptr())
+    call("w2e_pack_kq", ptr(w), ptr(wp), n, npad, k, k, 0, stream_ptr())
+    assert torch.equal(ap[:, :m].permute(1, 0, 2).reshape(m, k), a) and float(ap[:, m:].abs().sum()) == 0.0
+    wt = w.t().contiguous()  # [k, n]: the transposed packing must give the same operand
+    wp2 = torch.empty_like(wp)
+    call("w2e_pack_kq", ptr(wt), ptr(wp2), n, npad, k, n, 1, stream_ptr())
+    assert torch.equal(wp2, wp)
+    ref = a.double() @ w.double().t()
+    pick = _lib.load().w2e_gemm_pk_splits(m, n, k)
+    chunks = k // 8
+    tried = 0
+    for sp in sorted({1, 2, 3, 5, 8, pick}):
+        per = -(-(-(-chunks // sp)) // 4) * 4
+        if sp > chunks or (sp - 1) * per >= chunks:
+            continue
+        c = torch.full((sp, m, n), float("nan"), device=DEV)
+        call("w2e_gemm_pk", ptr(ap), ptr(wp), ptr(c), m, n, k, mpad, npad, n, sp, stream_ptr())
+        assert_close(c.double().sum(0), ref, 5e-6, f"gemm_pk, {sp} slabs")  # (fp32 sums over up to 3072 terms)
+        tried += 1
+    assert tried >= 2

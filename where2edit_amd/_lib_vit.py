@@ -11,13 +11,14 @@ PROTOS = {
     "w2e_layernorm_bwd_add": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "w2e_attn_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "w2e_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "w2e_gemm_fm_splits": (_I, [_I, _I, _I, _I]),
-    "w2e_gemm_fm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "w2e_reduce_gelu": (_I, [_P, _I, _L, _P, _P, _P, _P, _L, _I, _I, _P]),
-    "w2e_reduce_ln_fwd": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
-    "w2e_layernorm_bwd_part": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
-    "w2e_attn2_fwd": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P]),
-    "w2e_attn2_bwd": (_I, [_P, _I, _L, _P, _P, _I, _L, _P, _I, _I, _I, _P]),
+    "w2e_reduce_gelu": (_I, [_P, _I, _L, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "w2e_reduce_ln_fwd": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "w2e_layernorm_bwd_part": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P]),
+    "w2e_attn2_fwd": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _I, _P]),
+    "w2e_attn2_bwd": (_I, [_P, _I, _L, _P, _P, _I, _L, _P, _I, _I, _I, _I, _P]),
+    "w2e_pack_kq": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "w2e_gemm_pk": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "w2e_gemm_pk_splits": (_I, [_I, _I, _I]),
     "w2e_clip_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_clip_logits_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_step_loss_fwd": (_I, [_P, _I, _P, _P, _L, _F, _F, _P, _P]),

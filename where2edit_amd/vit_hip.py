@@ -239,133 +239,121 @@ def resblock_forward(blk, x, heads, arena=None):
                            arena)
 
 
-# ---------------------------------------------------------------------------------------------- second generation
-EPI_PLAIN, EPI_PARTIAL, EPI_GELU_DUAL, EPI_GELU_GRAD = 0, 1, 2, 3
-
-
-_SPLITS = {}
-
-
-def _fm_splits(m, n, k):
-    """K-splits for a gemm_fm shape (w2e_gemm_fm_splits: enough workgroups to fill the chip); 1 in deterministic mode is NOT
-    needed -- the slabs are summed in a fixed order by their consumer."""
-    key = (m, n, k)
-    if key not in _SPLITS:
-        from . import _lib
-        _SPLITS[key] = _lib.load().w2e_gemm_fm_splits(m, n, k, 1)
-    return _SPLITS[key]
-
-
-def _gemm_fm(a, w, epi=EPI_PLAIN, bias=None, aux=None, splits=1):
-    """C = A[M,K] x W[N,K]^T through w2e_gemm_fm.  PARTIAL: returns [splits, M, N] slabs; GELU_DUAL: (c, gelu(c))."""
-    m, k = a.shape
-    n = w.shape[0]
-    dev = a.device
-    c = torch.empty((splits, m, n) if epi == EPI_PARTIAL else (m, n), device=dev, dtype=torch.float32)
-    c2 = torch.empty((m, n), device=dev, dtype=torch.float32) if epi == EPI_GELU_DUAL else None
-    sp = profiling.span("vit_gemm", 2.0 * m * n * k)
-    call("w2e_gemm_fm", ptr(a), ptr(w), ptr(c), ptr(c2), m, n, k, a.stride(0), w.stride(0), n, splits, epi, ptr(bias), ptr(aux),
-         stream_ptr())
-    if sp is not None:
-        sp.end()
-    return (c, c2) if epi == EPI_GELU_DUAL else c
-
-
-def _reduce_ln(part, bias, residual, gamma, beta, eps, want_x=True, want_y=True):
-    """x = sum of the slabs (+ bias + residual); y = LayerNorm(x).  part: [S, M, D]."""
+# ---------------------------------------------------------------------------------------------- the M = 50*batch tower (csrc/vit2.hip, vit3.hip)
+def _reduce_ln(part, bias, residual, gamma, beta, eps, want_x=True, want_y=True, mpad=0):
+    """x = sum of the slabs (+ bias + residual); y = LayerNorm(x).  part: [S, M, D].  mpad > 0: y comes back K-quad-major
+    ([D/4, mpad, 4]: w2e_gemm_pk's A operand)."""
     s, m, d = part.shape
     dev = part.device
     x = torch.empty((m, d), device=dev, dtype=torch.float32) if want_x else None
     y = mean = rstd = None
     if want_y:
-        y = torch.empty((m, d), device=dev, dtype=torch.float32)
+        y = torch.empty((d // 4, mpad, 4) if mpad else (m, d), device=dev, dtype=torch.float32)
         mean = torch.empty(m, device=dev, dtype=torch.float32)
         rstd = torch.empty(m, device=dev, dtype=torch.float32)
     call("w2e_reduce_ln_fwd", ptr(part), s, m * d, ptr(bias), ptr(residual), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
-         ptr(rstd), m, d, float(eps), stream_ptr())
+         ptr(rstd), m, d, float(eps), mpad, stream_ptr())
     return x, y, mean, rstd
 
 
-def _ln_bwd_part(gpart, x, gamma, mean, rstd, add):
+def _ln_bwd_part(gpart, x, gamma, mean, rstd, add, mpad=0):
+    """gx = LN'(sum of the slabs) + add; mpad > 0: also its K-quad-major copy (the next GEMM's A operand): returns (gx, gx_packed)."""
     s, m, d = gpart.shape
     gx = torch.empty((m, d), device=gpart.device, dtype=torch.float32)
+    gxp = torch.empty((d // 4, mpad, 4), device=gpart.device, dtype=torch.float32) if mpad else None
     call("w2e_layernorm_bwd_part", ptr(gpart), s, m * d, ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(add), ptr(gx), m, d,
-         stream_ptr())
-    return gx
+         ptr(gxp), mpad, stream_ptr())
+    return (gx, gxp) if mpad else gx
 
 
-def _mlp_up(y, fc_w, fc_b):
-    """h = y W_fc^T + b, g = QuickGELU(h): one launch when the shape fills the chip unsplit, else split-K + w2e_reduce_gelu."""
-    m, n = y.shape[0], fc_w.shape[0]
-    sp = _fm_splits(m, n, y.shape[1])
-    if sp == 1:
-        return _gemm_fm(y, fc_w, EPI_GELU_DUAL, bias=fc_b)
-    part = _gemm_fm(y, fc_w, EPI_PARTIAL, splits=sp)
-    h = torch.empty((m, n), device=y.device, dtype=torch.float32)
-    g = torch.empty((m, n), device=y.device, dtype=torch.float32)
-    call("w2e_reduce_gelu", ptr(part), sp, m * n, ptr(fc_b), None, ptr(h), ptr(g), m, n, 0, stream_ptr())
-    return h, g
+# ---------------------------------------------------------------------------------------------- third-generation tower (csrc/vit3.hip)
+def _pad(v, q):
+    return -(-v // q) * q
 
 
-def _mlp_up_grad(gy, proj_wt, h):
-    """(gy W_proj) * QuickGELU'(h)."""
-    m, n = gy.shape[0], proj_wt.shape[0]
-    sp = _fm_splits(m, n, gy.shape[1])
-    if sp == 1:
-        return _gemm_fm(gy, proj_wt, EPI_GELU_GRAD, aux=h)
-    part = _gemm_fm(gy, proj_wt, EPI_PARTIAL, splits=sp)
-    out = torch.empty((m, n), device=gy.device, dtype=torch.float32)
-    call("w2e_reduce_gelu", ptr(part), sp, m * n, None, ptr(h), ptr(out), None, m, n, 1, stream_ptr())
-    return out
-
-
-class _WeightsT:
-    """Transposed copies of the frozen Linear weights for the input-gradient GEMMs (gx = gy W = gy (W^T)^T: gemm_fm wants
-    both operands with K contiguous).  +340 MB for ViT-B/32; rebuilt when a weight's version changes."""
+class _WeightsPk:
+    """K-quad-major packed copies of the frozen Linear weights (w2e_pack_kq): `fwd(w)` for y = x W^T (contraction over W's columns),
+    `bwd(w)` for gx = gy W (contraction over W's rows: the packed form of W^T).  Built once per weight version: +2 x 340 MB for ViT-B/32."""
 
     def __init__(self):
         self.cache = {}
 
-    def get(self, w):
+    def _get(self, w, transposed):
         key = (w.data_ptr(), w._version)
-        hit = self.cache.get(id(w))
+        hit = self.cache.get((id(w), transposed))
         if hit is None or hit[0] != key:
-            hit = (key, w.detach().t().contiguous())
-            self.cache[id(w)] = hit
+            wd = w.detach()
+            n, k = (wd.shape[1], wd.shape[0]) if transposed else (wd.shape[0], wd.shape[1])  # output columns, contraction length
+            npad = _pad(n, 64)
+            p = torch.empty((k // 4, npad, 4), device=w.device, dtype=torch.float32)
+            call("w2e_pack_kq", ptr(_c(wd)), ptr(p), n, npad, k, wd.stride(0), int(transposed), stream_ptr())
+            hit = (key, (p, n, k, npad))
+            self.cache[(id(w), transposed)] = hit
         return hit[1]
 
+    def fwd(self, w):
+        return self._get(w, False)
 
-class _TransformerV2(torch.autograd.Function):
-    """All residual blocks of the visual tower as ONE autograd node on the M = 50*batch kernels (csrc/vit2.hip): per block
-    7 launches forward (reduce+LN, QKV GEMM, attention, out-proj GEMM, reduce+LN, c_fc GEMM with the QuickGELU pair, c_proj
-    GEMM) and 7 backward; split-K slabs are summed by their consumers, never added atomically."""
+    def bwd(self, w):
+        return self._get(w, True)
+
+
+_PK_SPLITS = {}
+
+
+def _gemm_pk(a_packed, m, mpad, wpk):
+    """[S, m, n] slabs = A x W^T on w2e_gemm_pk: both operands K-quad-major, one independent wave per (32 rows, 64 columns, K slice)."""
+    wp, n, k, npad = wpk
+    key = (m, n, k)
+    if key not in _PK_SPLITS:
+        from . import _lib
+        _PK_SPLITS[key] = _lib.load().w2e_gemm_pk_splits(m, n, k)
+    sp = _PK_SPLITS[key]
+    c = torch.empty((sp, m, n), device=a_packed.device, dtype=torch.float32)
+    prof = profiling.span("vit_gemm", 2.0 * m * n * k)
+    call("w2e_gemm_pk", ptr(a_packed), ptr(wp), ptr(c), m, n, k, mpad, npad, n, sp, stream_ptr())
+    if prof is not None:
+        prof.end()
+    return c
+
+
+class _TransformerV3(torch.autograd.Function):
+    """All residual blocks of the visual tower as ONE autograd node on the M = 50*batch kernels: per block 7 launches forward (reduce+LN,
+    QKV GEMM, attention, out-proj GEMM, reduce+LN, c_fc GEMM, reduce + QuickGELU pair -- then c_proj's GEMM opens the next block's
+    reduce+LN) and 7 backward.  The four GEMMs run on w2e_gemm_pk: every tensor a GEMM consumes is WRITTEN K-quad-major by its producer
+    (LayerNorm, attention, the QuickGELU pair and their backward counterparts take a `packed_rows` argument), the weights are packed
+    once; split-K slabs are summed by their consumers in a fixed order, never added atomically."""
 
     @staticmethod
-    def forward(ctx, x, heads, wt, blocks):
+    def forward(ctx, x, heads, wpk, blocks):
         b, l, dim = x.shape
         m = b * l
+        mpad = _pad(m, 32)
         x2 = _c(x).reshape(m, dim)
         saved = []
         pend, pbias, pres = x2.view(1, m, dim), None, None
+        dev = x.device
         for blk in blocks:
             p = _block_params(blk)
             _frozen(*p)
             ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b = p
-            xr, y1, mean1, rstd1 = _reduce_ln(pend, pbias, pres, ln1_w, ln1_b, blk.ln_1.eps)
-            qkv = _gemm_fm(y1, in_w, EPI_PARTIAL, splits=_fm_splits(m, 3 * dim, dim))
-            att = torch.empty((m, dim), device=x.device, dtype=torch.float32)
-            call("w2e_attn2_fwd", ptr(qkv), qkv.shape[0], m * 3 * dim, ptr(in_b), ptr(att), b, l, heads, stream_ptr())
-            o = _gemm_fm(att, out_w, EPI_PARTIAL, splits=_fm_splits(m, dim, dim))
-            x_mid, y2, mean2, rstd2 = _reduce_ln(o, out_b, xr, ln2_w, ln2_b, blk.ln_2.eps)
-            h, g = _mlp_up(y2, fc_w, fc_b)
-            pend = _gemm_fm(g, proj_w, EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
+            xr, y1, mean1, rstd1 = _reduce_ln(pend, pbias, pres, ln1_w, ln1_b, blk.ln_1.eps, mpad=mpad)
+            qkv = _gemm_pk(y1, m, mpad, wpk.fwd(in_w))
+            att = torch.empty((dim // 4, mpad, 4), device=dev, dtype=torch.float32)
+            call("w2e_attn2_fwd", ptr(qkv), qkv.shape[0], m * 3 * dim, ptr(in_b), ptr(att), b, l, heads, mpad, stream_ptr())
+            o = _gemm_pk(att, m, mpad, wpk.fwd(out_w))
+            x_mid, y2, mean2, rstd2 = _reduce_ln(o, out_b, xr, ln2_w, ln2_b, blk.ln_2.eps, mpad=mpad)
+            hp = _gemm_pk(y2, m, mpad, wpk.fwd(fc_w))
+            n_fc = fc_w.shape[0]
+            h = torch.empty((m, n_fc), device=dev, dtype=torch.float32)
+            g = torch.empty((n_fc // 4, mpad, 4), device=dev, dtype=torch.float32)
+            call("w2e_reduce_gelu", ptr(hp), hp.shape[0], m * n_fc, ptr(fc_b), None, ptr(h), ptr(g), m, n_fc, 0, mpad, stream_ptr())
+            pend = _gemm_pk(g, m, mpad, wpk.fwd(proj_w))
             pbias, pres = proj_b, x_mid
             saved.append((xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h))
         out, _, _, _ = _reduce_ln(pend, pbias, pres, None, None, 0.0, want_y=False)
-        # (through save_for_backward, not as attributes: autograd's version checks, saved-tensor hooks and its own error on a
-        # second backward without retain_graph then apply to this node as to any other)
         ctx.save_for_backward(*[t for blk_saved in saved for t in blk_saved])
-        ctx.blocks, ctx.wt, ctx.geom = blocks, wt, (b, l, dim, heads)
+        ctx.blocks, ctx.wpk, ctx.geom = blocks, wpk, (b, l, dim, heads)
         return out.reshape(b, l, dim)
 
     @staticmethod
@@ -373,21 +361,28 @@ class _TransformerV2(torch.autograd.Function):
     def backward(ctx, gout):
         b, l, dim, heads = ctx.geom
         m = b * l
-        wt = ctx.wt
+        mpad = _pad(m, 32)
+        wpk = ctx.wpk
         g = _c(gout).reshape(m, dim)
+        dev = g.device
+        gp = torch.empty((dim // 4, mpad, 4), device=dev, dtype=torch.float32)  # the one stand-alone packing pass of a step
+        call("w2e_pack_kq", ptr(g), ptr(gp), m, mpad, dim, dim, 0, stream_ptr())
         flat = ctx.saved_tensors
         saved = [flat[8 * i:8 * i + 8] for i in range(len(ctx.blocks))]
         for blk, (xr, mean1, rstd1, qkv, x_mid, mean2, rstd2, h) in zip(reversed(ctx.blocks), reversed(saved)):
             ln1_w, _, in_w, in_b, out_w, _, ln2_w, _, fc_w, _, proj_w, _ = _block_params(blk)
-            gh = _mlp_up_grad(g, wt.get(proj_w), h)                                      # through c_proj and QuickGELU'
-            gy2 = _gemm_fm(gh, wt.get(fc_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 4 * dim))
-            g_mid = _ln_bwd_part(gy2, x_mid, ln2_w, mean2, rstd2, g)                     # through ln_2, + the residual branch
-            ga = _gemm_fm(g_mid, wt.get(out_w), EPI_PARTIAL, splits=_fm_splits(m, dim, dim))
-            gqkv = torch.empty((m, 3 * dim), device=g.device, dtype=torch.float32)
+            n_fc = fc_w.shape[0]
+            ghp = _gemm_pk(gp, m, mpad, wpk.bwd(proj_w))                                  # through c_proj ...
+            gh = torch.empty((n_fc // 4, mpad, 4), device=dev, dtype=torch.float32)
+            call("w2e_reduce_gelu", ptr(ghp), ghp.shape[0], m * n_fc, None, ptr(h), ptr(gh), None, m, n_fc, 1, mpad, stream_ptr())  # ... and QuickGELU'
+            gy2 = _gemm_pk(gh, m, mpad, wpk.bwd(fc_w))
+            g_mid, g_mid_p = _ln_bwd_part(gy2, x_mid, ln2_w, mean2, rstd2, g, mpad=mpad)   # through ln_2, + the residual branch
+            ga = _gemm_pk(g_mid_p, m, mpad, wpk.bwd(out_w))
+            gqkv = torch.empty((3 * dim // 4, mpad, 4), device=dev, dtype=torch.float32)
             call("w2e_attn2_bwd", ptr(qkv), qkv.shape[0], m * 3 * dim, ptr(in_b), ptr(ga), ga.shape[0], m * dim, ptr(gqkv), b, l, heads,
-                 stream_ptr())
-            gy1 = _gemm_fm(gqkv, wt.get(in_w), EPI_PARTIAL, splits=_fm_splits(m, dim, 3 * dim))
-            g = _ln_bwd_part(gy1, xr, ln1_w, mean1, rstd1, g_mid)                        # through ln_1, + the residual branch
+                 mpad, stream_ptr())
+            gy1 = _gemm_pk(gqkv, m, mpad, wpk.bwd(in_w))
+            g, gp = _ln_bwd_part(gy1, xr, ln1_w, mean1, rstd1, g_mid, mpad=mpad)           # through ln_1, + the residual branch
         return g.reshape(b, l, dim), None, None, None
 
 
@@ -412,9 +407,9 @@ def vision_forward(vit, image):
     x = torch.cat([vit.class_embedding.view(1, 1, width).expand(b, 1, width), x], dim=1) + vit.positional_embedding
     x = layer_norm(x, vit.ln_pre)
     if _v2_ok(vit, width):
-        if not hasattr(vit, "_wt"):
-            vit._wt = _WeightsT()
-        x = _TransformerV2.apply(x, vit.heads, vit._wt, list(vit.transformer.resblocks))
+        if not hasattr(vit, "_wpk"):
+            vit._wpk = _WeightsPk()
+        x = _TransformerV3.apply(x, vit.heads, vit._wpk, list(vit.transformer.resblocks))
     else:  # widths the M = 50*batch kernels are not instantiated for (the tests' tiny tower): first-generation kernels
         arena = None if os.environ.get("W2E_TUNE_NO_ARENA") else _ZeroArena(len(vit.transformer.resblocks), x.device)
         for blk in vit.transformer.resblocks:
