@@ -11,7 +11,7 @@ fam = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 for r in rows:
     name = r["Kernel_Name"]
-    key = ("w2e::modconv_kernel<*>" if "modconv_kernel" in name else "w2e::gemm_fm_kernel" if "gemm_fm" in name
+    key = ("w2e::modconv_kernel<*>" if "modconv_kernel" in name else "w2e::gemm_pk_kernel (ViT tower GEMM)" if "gemm_pk" in name
            else "w2e::wino4_gemm_kernel<*> (the Winograd-domain contraction)" if "wino4_gemm_kernel" in name
            else "w2e::wino4_fused3_kernel<*>" if "wino4_fused3" in name else None)
     if key is None:
