@@ -534,11 +534,11 @@ def main():
             executed = (d_flops + w_exec) / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "every 3x3 modulated conv call of the step, fwd + dgrad: w2e::modconv_kernel (fp32 MFMA "
                                "32x32x2 implicit GEMM: up-sampling convs, their stride-2 adjoints, <= 8^2 layers)" +
-                               (", the fused F(4x4,3x3) kernels (w2e::wino4_fused*) and the Winograd-domain contraction kernel "
-                                "(w2e::wino4_gemm_kernel) between w2e::wino4_input / its own output transform" if w_calls else ""),
+                               (", the fused F(4x4,3x3) kernel (w2e::wino4_fused3_kernel) and the Winograd-domain contraction kernel "
+                                "(w2e::wino4_gemm_kernel: w2e::wino4_pack_input_kernel in front of it, the output transform in its epilogue)" if w_calls else ""),
                                "achieved": executed, "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": executed / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                               "flops": "EXECUTED by the matrix pipes: direct form 2*K*N*9 per pixel; F(4x4,3x3) calls 36/144 of that, F(2x2,3x3) 16/36",
+                               "flops": "EXECUTED by the matrix pipes: direct form 2*K*N*9 per pixel; an F(4x4,3x3) call 36/144 of that",
                                "launches": calls, "avg_launch_ms": ms / calls, "flop_per_launch": (d_flops + w_exec) / calls,
                                "share_of_step": (ms / max(sampled, 1)) / (1e3 * dt / args.steps),
                                "timed_steps": sampled,
