@@ -152,9 +152,10 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
                    const float* dot_with, float* dot_out, int wgs, void* stream);
 
 /* ---- K1g  the F(4x4,3x3) form with the contraction on an OWN fp32-MFMA kernel and the output transform in its epilogue
- * (model.py:270-274; models/facial_recognition/helpers.py:97-119) -- the wide same-resolution layers (N % 64 == 0, K % 8 == 0,
- * H, W % 4 == 0).  Replaces the host-side composition w2e_wino_input -> vendor strided-batched GEMM -> w2e_wino_output:
- *   w2e_wino_gemm_plan   for one layer call: tiles_padded (T = batch*H/4*W/4 rounded up to 32), the K split the library would use
+ * (model.py:270-274; models/facial_recognition/helpers.py:97-119) -- the wide same-resolution layers (N % 64 == 0, K % 8 == 0;
+ * H, W multiples of 4 -- or not, with the plain and the bias + PReLU epilogues only: tiles then = ceil(H/4) * ceil(W/4) and the
+ * outputs of the last tile row / column past the image are not stored: IR-SE50's 14^2 / 7^2 stages).  Replaces the host-side composition w2e_wino_input -> vendor strided-batched GEMM -> w2e_wino_output:
+ *   w2e_wino_gemm_plan   for one layer call: tiles_padded (T = batch*ceil(H/4)*ceil(W/4) rounded up to 32), the K split the library would use
  *                        (1 = none; small layers split K so that 256 CUs have work) and the floats of `workspace` w2e_wino_gemm needs
  *                        (fused-dot partials + split-K slabs; may be 0).  vf must hold 36 * K * tiles_padded floats.
  *   w2e_wino_pack_input  x [B,K,H,W], in_scale [B,K] or NULL -> vf [36][K/8][2][tiles_padded][4]: B^T (in_scale * window) B in the

@@ -263,13 +263,15 @@ def test_config5_invert_and_edit_pipeline_matches_oracle(bsz):
 
 
 @pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 128, 28, 28), (4, 2, 256, 256, 28, 28), (4, 1, 64, 64, 112, 112), (4, 5, 128, 64, 56, 28),
-                                         (4, 16, 128, 256, 28, 28), (8, 2, 64, 64, 32, 64), (8, 3, 128, 256, 16, 32)])
+                                         (4, 16, 128, 256, 28, 28), (4, 16, 256, 256, 14, 14), (4, 8, 256, 256, 14, 14), (4, 3, 512, 512, 7, 7),
+                                         (4, 2, 64, 128, 10, 6), (8, 2, 64, 64, 32, 64), (8, 3, 128, 256, 16, 32)])
 def test_conv3x3_winograd_forms(m, b, k, n, h, w):
     """The stride-1 convs of the IR-SE50 / e4e encoders through the Winograd F(4x4,3x3) forms -- m = 4: the own contraction kernel
     (w2e_wino_pack_input + w2e_wino_gemm with the bias + PReLU epilogue of w2e_conv3x3, incl. the K split the plan picks for these small
     layers); m = 8: the fused kernel (w2e_wino_fused version 3) with the same epilogue: forward with BN scale, bias and PReLU, the
     input-gradient form (in_scale on the transposed + flipped pack), against float64 and against the direct kernel; tile counts per
-    image that are no multiple of 32 (196, 49) and totals that pad (49 x 3 = 147 -> 160)."""
+    image that are no multiple of 32 (196, 49) and totals that pad (49 x 3 = 147 -> 160); image sizes that are no multiple of 4 -- 14^2,
+    7^2 (IR-SE50's last two stages), 10 x 6: the ragged form, tiles hanging over the image, with and without a K split."""
     import torch.nn.functional as F
     from where2edit_amd import functional as K, irse_hip as I
     g = torch.Generator().manual_seed(5 * k + n + h)

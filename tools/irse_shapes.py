@@ -29,7 +29,7 @@ for B, Ci, C, H in shapes:
     run = lambda form: I.conv3x3(x, wp, C, H, H, bias=bias, slope=slope, form=form)
     base = timeit(lambda: run(0))
     res.append(f"direct {base:6.1f}us ({flop / base / 1e6:5.1f} TF/s)")
-    if K._gemm_shape_ok(B, Ci, C, H, H, dot=False):
+    if K._gemm_shape_ok(B, Ci, C, H, H, dot=False, ragged=True):
         t = timeit(lambda: run(4))
         res.append(f"F(4x4) gemm {t:6.1f}us ({flop / t / 1e6:5.1f})")
     if K._fused_shape_ok(B, Ci, C, H, H):

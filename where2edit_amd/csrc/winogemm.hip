@@ -32,9 +32,12 @@ typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------------- input transform
 // blockDim 256: lane pair (t, cp): tile t, channel pair cp of the float4 -> channels k = 8*kc + h + 2*(2*cp + e), e = 0, 1.
 // grid (ceil(TP / 128), 2 * K/8).  A wave stores 32 tiles x 16 B = 512 contiguous bytes per position.
+// RAGGED: H or W is not a multiple of 4 (IR-SE50's 14^2 / 7^2 stages): tiles = ceil(H/4) x ceil(W/4), the windows of the last tile row /
+// column run past the image and read zeros, rows are not 16-byte aligned: scalar loads (these tensors are small).
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void wino4_pack_input_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                                                float* __restrict__ vf, int B, int K, int H, int W, int TP) {
-    const int TX = W >> 2, TY = H >> 2, tiles = TX * TY;
+    const int TX = (W + 3) >> 2, TY = (H + 3) >> 2, tiles = TX * TY;
     const int T = B * tiles;
     const int cp = threadIdx.x & 1;
     const int t = blockIdx.x * 128 + (threadIdx.x >> 1);
@@ -55,8 +58,18 @@ __global__ __launch_bounds__(256) void wino4_pack_input_kernel(const float* __re
             const int iy = 4 * ty - 1 + r;
             const bool rin = iy >= 0 && iy < H;
             const float* row = xp + (int64_t)(rin ? iy : 0) * W + 4 * tx;
-            const float4 mid = rin ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float d[6] = {(rin && tx > 0) ? row[-1] : 0.f, mid.x, mid.y, mid.z, mid.w, (rin && tx + 1 < TX) ? row[4] : 0.f};
+            float d[6];
+            if (RAGGED) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int ix = 4 * tx - 1 + c;
+                    d[c] = (rin && ix >= 0 && ix < W) ? row[c - 1] : 0.f;
+                }
+            } else {
+                const float4 mid = rin ? *reinterpret_cast<const float4*>(row) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[0] = (rin && tx > 0) ? row[-1] : 0.f, d[1] = mid.x, d[2] = mid.y, d[3] = mid.z, d[4] = mid.w;
+                d[5] = (rin && tx + 1 < TX) ? row[4] : 0.f;
+            }
             wino4_bt(d, tr[r]);
         }
 #pragma unroll
@@ -95,8 +108,11 @@ struct WinoGemmArgs {
 
 // ACT: 0 none; 1 = + noise_w*noise + bias, LeakyReLU(0.2) * sqrt 2; 2 = + bias, PReLU(slope) -- as wino4_output_kernel of round 3.
 // PART: K split -- the raw A^T M A of this split goes to slab z, no scale / epilogue (wino_finish_kernel applies them).
-template <int ACT, bool DOT, bool PART>
+// RAGGED: H or W not a multiple of 4 -- the tiles of the last row / column hang over the image and their outputs past it are not stored
+// (scalar stores: the rows are not 16-byte aligned); no fused dot in this form.
+template <int ACT, bool DOT, bool PART, bool RAGGED = false>
 __global__ __launch_bounds__(512) void wino4_gemm_kernel(const WinoGemmArgs p) {
+    static_assert(!(RAGGED && DOT), "the ragged form has no fused dot");
     constexpr int MS = 36 * 16 * 32;  // floats of one exchange buffer M[36][16][32]
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // M[2][MS]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const WinoGemmArgs p) {
     // = rows 8*q4 .. 8*q4+7 of each wave's 32-channel half into M[xi][hh*8 + 4*half + rr][j].
     const int oj = tid & 31, on16 = tid >> 5;  // item: tile oj of the block, row on16 of the round (channel half on16 >> 3, row on16 & 7)
     const int H = p.H, W = p.W;
-    const int TX = W >> 2, tiles = TX * (H >> 2);
+    const int TX = (W + 3) >> 2, tiles = TX * ((H + 3) >> 2);
     const int t = t0 + oj;
     const bool live = t < p.T;
     const int tc = live ? t : p.T - 1;
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const WinoGemmArgs p) {
     float4 nz[4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
-        nz[ii] = (ACT == 1 && p.noise) ? *reinterpret_cast<const float4*>(p.noise + pix + (int64_t)ii * W) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nz[ii] = (ACT == 1 && p.noise && !RAGGED) ? *reinterpret_cast<const float4*>(p.noise + pix + (int64_t)ii * W) : make_float4(0.f, 0.f, 0.f, 0.f);
     float* const ybase = PART ? p.y + (int64_t)z * p.B * N * H * W : p.y;
     if (skip & 8) return;
 #pragma unroll
@@ -228,7 +244,16 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const WinoGemmArgs p) {
                 r.x = r.x > 0.f ? r.x : sl * r.x, r.y = r.y > 0.f ? r.y : sl * r.y;
                 r.z = r.z > 0.f ? r.z : sl * r.z, r.w = r.w > 0.f ? r.w : sl * r.w;
             }
-            if (live) *reinterpret_cast<float4*>(ybase + plane * H * W + pix + (int64_t)ii * W) = r;
+            if (RAGGED) {
+                float* const yr = ybase + plane * H * W + pix + (int64_t)ii * W;
+                const bool rok = live && 4 * ty + ii < H;
+                if (rok && 4 * tx + 0 < W) yr[0] = r.x;
+                if (rok && 4 * tx + 1 < W) yr[1] = r.y;
+                if (rok && 4 * tx + 2 < W) yr[2] = r.z;
+                if (rok && 4 * tx + 3 < W) yr[3] = r.w;
+            } else if (live) {
+                *reinterpret_cast<float4*>(ybase + plane * H * W + pix + (int64_t)ii * W) = r;
+            }
         }
         if (DOT) {  // dot_part[plane][segment] = sum over the lanes of this half-wave that share (b, n): fixed order, no atomics
             if (!live) part = 0.f;
@@ -256,6 +281,19 @@ __global__ __launch_bounds__(256) void wino_finish_kernel(const float* __restric
     const float sl = (ACT == 2 && slope) ? slope[n] : 1.f;
     const int64_t slab = (int64_t)planes * HW, base = (int64_t)plane * HW;
     float part = 0.f;
+    if (HW & 3) {  // (planes that are not whole float4s: IR-SE50's 7^2 stage.  No noise / fused dot there: act 0 or 2)
+        for (int i = lane; i < HW; i += 64) {
+            float c = slabs[base + i];
+            for (int z = 1; z < S; ++z) c += slabs[(int64_t)z * slab + base + i];
+            float r = c * os;
+            if (ACT == 2) {
+                r += bs;
+                r = r > 0.f ? r : sl * r;
+            }
+            y[base + i] = r;
+        }
+        return;
+    }
     for (int i = lane * 4; i < HW; i += 256) {
         float4 c = *reinterpret_cast<const float4*>(slabs + base + i);
         for (int z = 1; z < S; ++z) {
@@ -297,7 +335,7 @@ __global__ __launch_bounds__(256) void wino_dot_sum_kernel(const float* __restri
 }
 
 static int plan(int batch, int k_ch, int n_ch, int h, int w, int* tp, int* splits, int64_t* ws_floats, int* nseg_out, int force_splits) {
-    const int tiles = (h / 4) * (w / 4);
+    const int tiles = ((h + 3) / 4) * ((w + 3) / 4);
     const int64_t T = (int64_t)batch * tiles;
     const int64_t TP = (T + 31) & ~(int64_t)31;
     const int KC = k_ch / 8;
@@ -328,8 +366,8 @@ extern "C" {
 int w2e_wino_gemm_plan(int batch, int k_ch, int n_ch, int h, int w, int* tiles_padded, int* splits, int64_t* workspace_floats) {
     W2E_REQUIRE(tiles_padded && splits && workspace_floats, "wino_gemm_plan: null output");
     W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && n_ch > 0 && (n_ch & 63) == 0, "wino_gemm_plan: K %% 8 == 0, N %% 64 == 0 (got %d, %d)", k_ch, n_ch);
-    W2E_REQUIRE(h >= 4 && w >= 4 && (h & 3) == 0 && (w & 3) == 0, "wino_gemm_plan: H, W multiples of 4 (got %d x %d)", h, w);
-    W2E_REQUIRE((int64_t)batch * (h / 4) * (w / 4) < ((int64_t)1 << 30), "wino_gemm_plan: too many tiles");
+    W2E_REQUIRE(h >= 4 && w >= 4, "wino_gemm_plan: H, W >= 4 (got %d x %d)", h, w);
+    W2E_REQUIRE((int64_t)batch * ((h + 3) / 4) * ((w + 3) / 4) < ((int64_t)1 << 30), "wino_gemm_plan: too many tiles");
     int nseg = 0;
     plan(batch, k_ch, n_ch, h, w, tiles_padded, splits, workspace_floats, &nseg, 0);
     return 0;
@@ -337,15 +375,16 @@ int w2e_wino_gemm_plan(int batch, int k_ch, int n_ch, int h, int w, int* tiles_p
 
 int w2e_wino_pack_input(const float* x, const float* in_scale, float* vf, int batch, int k_ch, int h, int w, int tiles_padded, void* stream) {
     W2E_REQUIRE(x && vf, "wino_pack_input: null tensor");
-    W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && h >= 4 && w >= 4 && (h & 3) == 0 && (w & 3) == 0,
-                "wino_pack_input: K %% 8 == 0 and H, W multiples of 4 (got K %d, %d x %d)", k_ch, h, w);
+    W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && h >= 4 && w >= 4, "wino_pack_input: K %% 8 == 0 and H, W >= 4 (got K %d, %d x %d)", k_ch, h, w);
+    const bool ragged = (h & 3) != 0 || (w & 3) != 0;
     W2E_REQUIRE((((uintptr_t)x | (uintptr_t)vf) & 15) == 0, "wino_pack_input: x / vf must be 16-byte aligned");
-    const int64_t T = (int64_t)batch * (h / 4) * (w / 4);
+    const int64_t T = (int64_t)batch * ((h + 3) / 4) * ((w + 3) / 4);
     W2E_REQUIRE(tiles_padded >= T && (tiles_padded & 31) == 0, "wino_pack_input: tiles_padded %d for %lld tiles (w2e_wino_gemm_plan)", tiles_padded, (long long)T);
     W2E_REQUIRE((int64_t)36 * k_ch * tiles_padded * 4 < ((int64_t)1 << 32) - 64, "wino_pack_input: V exceeds 4 GB");
     if (batch == 0) return 0;
     dim3 grid((unsigned)ceil_div(T, 128), (unsigned)(k_ch / 8 * 2));
-    wino4_pack_input_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, in_scale, vf, batch, k_ch, h, w, tiles_padded);
+    if (ragged) wino4_pack_input_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, in_scale, vf, batch, k_ch, h, w, tiles_padded);
+    else wino4_pack_input_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, in_scale, vf, batch, k_ch, h, w, tiles_padded);
     W2E_LAUNCH_CHECK("wino_pack_input");
     return 0;
 }
@@ -356,7 +395,9 @@ int w2e_wino_gemm(const float* uf, const float* vf, const float* out_scale, floa
     W2E_REQUIRE(uf && vf && y, "wino_gemm: null tensor");
     W2E_REQUIRE(act >= 0 && act <= 2, "wino_gemm: epilogue %d (0 none, 1 StyledConv, 2 bias + PReLU)", act);
     W2E_REQUIRE(batch >= 0 && k_ch > 0 && (k_ch & 7) == 0 && n_ch > 0 && (n_ch & 63) == 0, "wino_gemm: K %% 8 == 0, N %% 64 == 0 (got %d, %d)", k_ch, n_ch);
-    W2E_REQUIRE(h >= 4 && w >= 4 && (h & 3) == 0 && (w & 3) == 0, "wino_gemm: H, W multiples of 4 (got %d x %d)", h, w);
+    W2E_REQUIRE(h >= 4 && w >= 4, "wino_gemm: H, W >= 4 (got %d x %d)", h, w);
+    const bool ragged = (h & 3) != 0 || (w & 3) != 0;  // tiles = ceil(H/4) x ceil(W/4); outputs past the image are not stored
+    W2E_REQUIRE(!ragged || (!dot_with && act != 1), "wino_gemm: H, W that are not multiples of 4 take the plain and the bias + PReLU epilogues only");
     W2E_REQUIRE(!(act && dot_with), "wino_gemm: the activation epilogues and the fused dot exclude each other");
     W2E_REQUIRE(!dot_with || dot_out, "wino_gemm: dot_with without dot_out");
     W2E_REQUIRE(!noise || noise_w, "wino_gemm: noise without noise_w");
@@ -365,7 +406,7 @@ int w2e_wino_gemm(const float* uf, const float* vf, const float* out_scale, floa
     W2E_REQUIRE((((uintptr_t)uf | (uintptr_t)vf | (uintptr_t)y | (uintptr_t)(dot_with ? dot_with : y) | (uintptr_t)(noise ? noise : y) |
                   (uintptr_t)(workspace ? workspace : y)) & 15) == 0, "wino_gemm: uf / vf / y / dot_with / noise / workspace must be 16-byte aligned");
     if (batch == 0) return 0;
-    const int tiles = (h / 4) * (w / 4);
+    const int tiles = ((h + 3) / 4) * ((w + 3) / 4);
     const int64_t T = (int64_t)batch * tiles;
     W2E_REQUIRE(T < ((int64_t)1 << 30), "wino_gemm: too many tiles");
     W2E_REQUIRE(tiles_padded >= T && (tiles_padded & 31) == 0, "wino_gemm: tiles_padded %d for %lld tiles (w2e_wino_gemm_plan)", tiles_padded, (long long)T);
@@ -376,7 +417,7 @@ int w2e_wino_gemm(const float* uf, const float* vf, const float* out_scale, floa
     W2E_REQUIRE(!dot_with || (tiles & 31) == 0 || (tiles < 32 && (tiles & (tiles - 1)) == 0), "wino_gemm: fused dot with %d tiles per plane (a multiple of 32, or a power of two below it)", tiles);
     const int nseg = tiles >= 32 ? tiles / 32 : 1;
     W2E_REQUIRE(!(dot_with || splits > 1) || workspace, "wino_gemm: the fused dot and a split K need the workspace of w2e_wino_gemm_plan");
-    W2E_REQUIRE(splits == 1 || (int64_t)h * w % 4 == 0, "wino_gemm: split planes must be whole float4s");
+    W2E_REQUIRE(splits == 1 || (int64_t)h * w % 4 == 0 || (!dot_with && act != 1), "wino_gemm: split planes that are not whole float4s take the plain and the bias + PReLU epilogues only");
     hipStream_t s = (hipStream_t)stream;
     WinoGemmArgs a;
     a.uf = uf, a.vf = vf, a.out_scale = out_scale, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.slope = slope, a.dot_with = dot_with;
@@ -394,17 +435,21 @@ int w2e_wino_gemm(const float* uf, const float* vf, const float* out_scale, floa
     W2E_REQUIRE(gx < ((int64_t)1 << 31), "wino_gemm: grid too large");
     const dim3 grid((unsigned)gx);
     const size_t lds = (size_t)2 * 36 * 16 * 32 * 4;
-    static unsigned done[5];
-#define W2E_WG(ACTv, DOTv, PARTv, slot)                                                                                               \
+    static unsigned done[8];
+#define W2E_WG(ACTv, DOTv, PARTv, RAGv, slot)                                                                                         \
     do {                                                                                                                             \
-        W2E_REQUIRE(big_lds_once((const void*)wino4_gemm_kernel<ACTv, DOTv, PARTv>, &done[slot]), "wino_gemm: cannot enable %zu B of LDS", lds); \
-        wino4_gemm_kernel<ACTv, DOTv, PARTv><<<grid, 512, lds, s>>>(a);                                                               \
+        W2E_REQUIRE(big_lds_once((const void*)wino4_gemm_kernel<ACTv, DOTv, PARTv, RAGv>, &done[slot]), "wino_gemm: cannot enable %zu B of LDS", lds); \
+        wino4_gemm_kernel<ACTv, DOTv, PARTv, RAGv><<<grid, 512, lds, s>>>(a);                                                         \
     } while (0)
-    if (splits > 1) W2E_WG(0, false, true, 4);
-    else if (act == 1) W2E_WG(1, false, false, 0);
-    else if (act == 2) W2E_WG(2, false, false, 1);
-    else if (dot_with) W2E_WG(0, true, false, 2);
-    else W2E_WG(0, false, false, 3);
+    if (ragged) {
+        if (splits > 1) W2E_WG(0, false, true, true, 5);
+        else if (act == 2) W2E_WG(2, false, false, true, 6);
+        else W2E_WG(0, false, false, true, 7);
+    } else if (splits > 1) W2E_WG(0, false, true, false, 4);
+    else if (act == 1) W2E_WG(1, false, false, false, 0);
+    else if (act == 2) W2E_WG(2, false, false, false, 1);
+    else if (dot_with) W2E_WG(0, true, false, false, 2);
+    else W2E_WG(0, false, false, false, 3);
 #undef W2E_WG
     W2E_LAUNCH_CHECK("wino_gemm");
     const int planes = batch * n_ch;

@@ -288,11 +288,14 @@ def _fused_shape_ok(b, k, n, h, w, dot=False):
     return 32 <= k <= 256 and k & (k - 1) == 0 and 4 * b * k * h * w < X_LIMIT
 
 
-def _gemm_shape_ok(b, k, n, h, w, dot=True):
-    """w2e_wino_gemm's shape rules (include/w2e.h, K1g)."""
-    if b <= 0 or k % 8 or n % 64 or h % 4 or w % 4:
+def _gemm_shape_ok(b, k, n, h, w, dot=True, ragged=False):
+    """w2e_wino_gemm's shape rules (include/w2e.h, K1g).  `ragged`: the caller accepts the form for H, W that are not multiples of 4
+    (tiles hang over the image; plain and bias + PReLU epilogues only: the encoders' 14^2 / 7^2 stages)."""
+    if b <= 0 or k % 8 or n % 64 or h < 4 or w < 4:
         return False
-    tiles = (h // 4) * (w // 4)
+    if (h % 4 or w % 4) and (dot or not ragged):
+        return False
+    tiles = -(-h // 4) * -(-w // 4)
     tp = (b * tiles + 31) & ~31
     if 36 * k * tp * 4 >= X_LIMIT or 36 * k * n * 4 >= X_LIMIT or b * tiles >= 2 ** 30:
         return False
@@ -348,7 +351,7 @@ def wino_gemm_conv(x, wp, in_scale, out_scale, y, k, n, h, w, act_code=0, noise=
         splits = min(GEMM_SPLITS, k // 8)
         kcs = -(-(k // 8) // splits)
         splits = -(-(k // 8) // kcs)
-        ws_floats = b * n * max(1, (h // 4) * (w // 4) // 32) + (splits * b * n * h * w if splits > 1 else 0)
+        ws_floats = b * n * max(1, -(-h // 4) * -(-w // 4) // 32) + (splits * b * n * h * w if splits > 1 else 0)
     if WINO_LOG is not None:
         WINO_LOG.append(f"{tag} (winograd F(4x4,3x3) gemm{', dot' if dot_with is not None else ''}) K {k} N {n} {h}x{w} B {b} -> "
                         f"36 x [{n}x{k}] x [{k}x{tp.value}], {splits} K split(s)")

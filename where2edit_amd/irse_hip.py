@@ -44,9 +44,9 @@ FUSED_ENCODER = os.environ.get("W2E_FUSED_ENCODER", "1") != "0"  # (A/B aid: the
 
 def _wino_form(b, k, n, h, w):
     """The Winograd F(4x4,3x3) form (functional.py, K1w / K1g) of one stride-1 3x3 conv of the IR-SE50 / e4e encoders, or 0: the fused kernel
-    for the narrow high-resolution stages, the GEMM form (own MFMA contraction, output transform in its epilogue) where the image divides
-    into 4x4 tiles and the channel counts allow, the direct kernel for the 64-channel 112^2-network stages, for 14^2 / 7^2 and where the
-    call is too small to pay for two launches (profiles/r03_irse_shapes.txt, r04_irse_shapes.txt)."""
+    for the narrow high-resolution stages, the GEMM form (own MFMA contraction, output transform in its epilogue) where the channel counts
+    allow -- also for 14^2 / 7^2, whose last tile row / column hangs over the image (the ragged form) --, the direct kernel where the call
+    is too small to pay for two or three launches (profiles/r04_irse_shapes.txt)."""
     if K.WINOGRAD is False:
         return 0
     if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0:
@@ -54,12 +54,12 @@ def _wino_form(b, k, n, h, w):
     # Measured per shape (profiles/r04_irse_shapes.txt; batch 8 of the e4e encoder / batch 16 of the id-loss network, us, direct / GEMM
     # form / fused): 64 -> 64 @ 256^2 302 / 254 / 167; 64 -> 64 @ 128^2 81 / 49 / 45; 64 -> 128 @ 128^2 147 / 72 / 86; 128 -> 128 @ 64^2
     # 80 / 53 / 41; 128 -> 256 @ 64^2 150 / 57 / 77; 256 -> 256 @ 32^2 88 / 45 / 70; 64 -> 64 @ 112^2 (batch 16) 162 / 87 / -;
-    # 64 -> 128 @ 56^2 87 / 42; 128 -> 256 @ 28^2 80 / 55; below ~3 GFLOP of direct work per call the direct kernel wins (64 -> 64 @ 56^2,
-    # batch 8: 26 / 39).  The fused kernel repeats its input transform per 32 output channels, the GEMM form pays one pass over V:
+    # 64 -> 128 @ 56^2 87 / 42; 128 -> 256 @ 28^2 80 / 55; 256 -> 256 @ 14^2 54 / 45; 256 -> 512 @ 14^2 89 / 53; 512 -> 512 @ 7^2 65 / 50;
+    # below ~3 GFLOP of direct work per call the direct kernel wins (64 -> 64 @ 56^2, batch 8: 26 / 39; 256 -> 256 @ 14^2, batch 8: 33 / 42).  The fused kernel repeats its input transform per 32 output channels, the GEMM form pays one pass over V:
     # fused where the layer does not widen (N <= K <= 128), the GEMM form otherwise.
     work_ok = 18.0 * b * k * n * h * w >= 3e9
     fused_ok = FUSED_ENCODER and K._fused_shape_ok(b, k, n, h, w)
-    gemm_ok = K._gemm_shape_ok(b, k, n, h, w, dot=False)
+    gemm_ok = K._gemm_shape_ok(b, k, n, h, w, dot=False, ragged=True)
     if K.WINOGRAD == K.FUSED:
         return K.FUSED if fused_ok else 0
     if K.WINOGRAD == 4:
