@@ -9,7 +9,7 @@ TAG=${1:-r4}
 O=$GRAFT_REPO_ROOT/gpurun_out/ev_$TAG
 R=/tmp/w2e_prof_$TAG
 rm -rf $O $R; mkdir -p $O $R
-timeout -k 10 400 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
+SECONDS=0; timeout -k 10 400 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err; echo "default bench.py run: $SECONDS s wall" > $O/bench_line_wall.txt
 echo bench done
 timeout -k 10 300 python3 bench.py --workload 3 --batch 8 --no-cpu-baseline --no-preview --no-config3 --no-config5 --no-n1-b8 > $O/bench_line_w3_b8.json 2> $O/bench_line_w3_b8.err || true
 timeout -k 10 300 python3 bench.py --workload 2 --batch 8 --no-cpu-baseline --no-preview --no-config3 --no-config5 --no-n1-b8 > $O/bench_line_w2_b8.json 2> $O/bench_line_w2_b8.err || true
