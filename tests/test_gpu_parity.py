@@ -955,6 +955,48 @@ def test_trainable_decoder_weights_are_refused_not_run_on_a_second_backend():
     assert_close(ig2, io, FWD_TOL, "image with frozen conv weights")
 
 
+def test_wino_gemm_edge_shapes_and_argument_errors():
+    """w2e_wino_gemm at the edges of its contract: the smallest legal layer (K = 8: one chunk, N = 64, one 4 x 4 image = one tile in a
+    32-tile block), an empty batch, a K split that equals the chunk count, and the argument errors a caller can provoke (N % 64, a split
+    count that leaves an empty slice, the fused dot on a tile count it cannot segment, noise on a ragged image) -- refused with a message,
+    never launched."""
+    import torch.nn.functional as F
+    from where2edit_amd import functional as K
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    for (b, k, n, h, w, sp) in ((1, 8, 64, 4, 4, 0), (2, 32, 64, 8, 4, 4), (0, 64, 64, 16, 16, 0)):
+        wt = torch.randn(n, k, 3, 3, generator=g).to(DEV)
+        x = torch.randn(b, k, h, w, generator=g).to(DEV)
+        pack = K.conv_pack(wt, 1.0, False, False)
+        y = torch.full((b, n, h, w), 3.0, device=DEV)
+        saved = K.GEMM_SPLITS
+        K.GEMM_SPLITS = sp
+        try:
+            if b:
+                K.wino_gemm_conv(x, pack, None, None, y, k, n, h, w)
+        finally:
+            K.GEMM_SPLITS = saved
+        if b:
+            assert_close(y, F.conv2d(x.double(), wt.double(), padding=1), FWD_TOL, f"wino gemm {b}x{k}->{n}@{h}x{w}")
+    wt = torch.randn(64, 64, 3, 3, generator=g).to(DEV)
+    x = torch.randn(2, 64, 16, 16, generator=g).to(DEV)
+    uf = K._wino_weights_fused(K.conv_pack(wt, 1.0, False, False), 64, 64)
+    vf, y, ws = torch.empty(36 * 64 * 32, device=DEV), torch.empty(2, 64, 16, 16, device=DEV), torch.empty(1 << 20, device=DEV)
+    ok = ("w2e_wino_gemm", ptr(uf), ptr(vf), None, ptr(y), 2, 64, 64, 16, 16, 32, 1, ptr(ws), 0, None, None, None, None, None, None, stream_ptr())
+    call("w2e_wino_pack_input", ptr(x), None, ptr(vf), 2, 64, 16, 16, 32, stream_ptr())
+    call(*ok)
+    for index, value in ((7, 48), (11, 9), (10, 5)):  # n_ch = 48 (N % 64), 9 splits of 8 chunks, tiles_padded = 5 for 32 tiles
+        args = list(ok)
+        args[index] = value
+        with pytest.raises(RuntimeError, match="wino_gemm"):
+            call(*args)
+    dw = torch.randn(2, 64, 12, 12, generator=g).to(DEV)  # 9 tiles per plane: neither a multiple of 32 nor a power of two
+    with pytest.raises(RuntimeError, match="fused dot"):
+        call("w2e_wino_gemm", ptr(uf), ptr(vf), None, ptr(y), 2, 64, 64, 12, 12, 32, 1, ptr(ws), 0, None, None, None, None, ptr(dw), ptr(ws), stream_ptr())
+    with pytest.raises(RuntimeError, match="not multiples of 4"):
+        call("w2e_wino_gemm", ptr(uf), ptr(vf), None, ptr(y), 2, 64, 64, 14, 14, 32, 1, ptr(ws), 1, ptr(dw), ptr(ws), None, None, None, None, stream_ptr())
+
+
 @pytest.mark.parametrize("m,b,k,n,h,w", [(4, 3, 64, 64, 16, 16), (4, 1, 64, 128, 32, 32), (4, 2, 512, 512, 32, 32), (4, 5, 128, 64, 64, 32),
                                          (4, 2, 128, 128, 16, 32), (4, 1, 192, 64, 8, 16),
                                          (11, 2, 512, 512, 16, 16), (11, 3, 64, 64, 16, 16), (11, 1, 128, 64, 32, 64), (12, 2, 256, 128, 32, 32),
