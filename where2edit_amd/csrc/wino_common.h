@@ -7,8 +7,9 @@
 
 namespace w2e {
 
-__device__ __forceinline__ void wino4_bt(const float (&d)[6], float (&t)[6]) {  // t = B^T d
-    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+template <class T>
+__device__ __forceinline__ void wino4_bt(const T (&d)[6], T (&t)[6]) {  // t = B^T d  (T: float, or a float2 vector -> v_pk_*_f32)
+    const T a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
     t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
     t[1] = a + b;
     t[2] = a - b;
@@ -17,8 +18,9 @@ __device__ __forceinline__ void wino4_bt(const float (&d)[6], float (&t)[6]) {  
     t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
 
-__device__ __forceinline__ void wino4_at(const float (&m)[6], float (&y)[4]) {  // y = A^T m
-    const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+template <class T>
+__device__ __forceinline__ void wino4_at(const T (&m)[6], T (&y)[4]) {  // y = A^T m
+    const T p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
     y[0] = m[0] + p + r;
     y[1] = q + 2.f * s;
     y[2] = p + 4.f * r;

@@ -11,6 +11,8 @@
 // pass and the first two generations of the fused kernel are gone (profiles/r03_winograd.txt keeps their measurements).
 // fp32 throughout; the transforms multiply by up to 8 and 1/24: ~1e-5 max-norm relative to a float64 convolution at K = 128 ... 512
 // (direct form 3e-7) -- two decades inside the path's 1e-3 tolerance (BASELINE north_star), one inside the tests' 1e-4.
+#include <type_traits>
+
 #include "common.h"
 #include "wino_common.h"
 #include "../../include/w2e.h"
@@ -58,6 +60,8 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
 }
 
 typedef float wf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float wf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float wf_f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ F(4x4, 3x3), fused, persistent, patch staged by LDS-DMA
 // One persistent workgroup = 4 matrix waves + 4 transform waves in lock-step ticks (one barrier each; two separate loops with the same
@@ -68,8 +72,8 @@ typedef float wf_f32x16 __attribute__((ext_vector_type(16)));
 // [8 ch][18 rows][10 quads] floats, image columns bx*32-4 .. bx*32+35 so that every 16-byte quad is either wholly inside the image
 // row or wholly outside it (zero padding = an out-of-range offset, exact) -- by `buffer_load_dwordx4 ... lds` into a ring of three
 // stages, three chunks ahead of the MFMAs, with explicit vmcnt counts: no registers, no compiler-managed waits, 6 DMA instructions per
-// wave and chunk instead of 18 window loads per thread.  A transform thread reads its 6x6 window from the stage (one ds_read_b128 +
-// two ds_read_b32 per row).  Per block: a pre-tick (chunk 0 -> V[0]), KC matrix ticks (MFMAs of chunk c | transform of chunk c+1,
+// wave and chunk instead of 18 window loads per thread.  A transform thread owns one tile, a channel PAIR and half of the 36 positions,
+// in packed fp32 (v_pk_*_f32: see `transform_h`).  Per block: a pre-tick (chunk 0 -> V[0]), KC matrix ticks (MFMAs of chunk c | transform of chunk c+1,
 // DMA of chunk g+3), then two output rounds of 16 channels through the V space, in which all 512 threads own a (channel, tile) pair.
 // TXN: tiles of a block along x (8: blocks of 32 x 16 pixels; 16: 64 x 8 -- longer row segments per DMA, fewer cache lines per byte).
 template <int ACT, bool DOT, int TXN>
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     if (wave >= 4) {
         // ---------------------------------------------------------------------------------------------- transform waves
         const int tw = wave - 4;
-        const int tj = tid & 31, tch = (tid >> 5) & 7;  // tile of a block, channel of a chunk
+        const int tj = tid & 31;  // tile of a block
         const uint64_t a64 = (uint64_t)(uintptr_t)x;
         i32x4 qx;
         qx[0] = (int)(unsigned)a64, qx[1] = (int)(unsigned)((a64 >> 32) & 0xffffu), qx[2] = (int)(unsigned)((int64_t)B * K * H * W * 4), qx[3] = 0x00020000;
@@ -207,25 +211,54 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             }
 #endif
         };
-        auto transform = [&](int bi, int kc, int g) __attribute__((always_inline)) {  // chunk (bi, kc) = global g: ring stage g % 3 -> V[kc & 1]
-            const float sc = sctab[(bi & 1) * 256 + kc * 8 + tch];
-            const float* pp = ring + (g % 3) * PS + tch * 720 + (4 * (tj / TXN)) * PC + 4 * (tj % TXN);
-            float t[6][6];
+        // chunk (bi, kc) = global g: ring stage g % 3 -> V[kc & 1], in PACKED fp32 (v_pk_*_f32).  What a partner wave issues beside a
+        // saturated fp32 matrix pipe is one instruction per ~22 cycles of ANY kind (tools/pk_probe.hip, profiles/r04_pk_probe.txt): the
+        // transform's instruction COUNT is its cost.  A thread owns one tile, the channel PAIR (chA, chA + 2) of the chunk -- the
+        // float2 (c0, c0 + 1) of V's operand quad -- and HALF of the 36 positions (columns jj = 3 hf .. 3 hf + 2 of the transform domain:
+        // the row pass yields 3 of its 6 outputs from 5 of the 6 window columns; hf is wave-uniform and compile-time inside).  The
+        // patch columns 4 .. 7 of each channel come as one conflict-free 16-byte read, v_pk_mov_b32 pairs the channels.
+        const int hfw = tw & 1, cpair = (lane >> 5) + 2 * (tw >> 1);
+        const int chA = 4 * (cpair >> 1) + (cpair & 1);  // = 2 c0 + h with h = cpair & 1, c0 = 2 (cpair >> 1); chB = chA + 2
+        auto transform_h = [&](auto hf_c, int bi, int kc, int g) __attribute__((always_inline)) {
+            constexpr int hf = decltype(hf_c)::value;
+            const wf_f32x2 sc = wf_f32x2{sctab[(bi & 1) * 256 + kc * 8 + chA], sctab[(bi & 1) * 256 + kc * 8 + chA + 2]};
+            const float* pp = ring + (g % 3) * PS + chA * 720 + (4 * (tj / TXN)) * PC + 4 * (tj % TXN);
+            wf_f32x2 t[6][3];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const float4 mid = *reinterpret_cast<const float4*>(pp + r * PC + 4);
-                const float d[6] = {pp[r * PC + 3], mid.x, mid.y, mid.z, mid.w, pp[r * PC + 8]};
-                wino4_bt(d, t[r]);
+                const wf_f32x4 ma = *reinterpret_cast<const wf_f32x4*>(pp + r * PC + 4), mb = *reinterpret_cast<const wf_f32x4*>(pp + r * PC + 4 + 1440);
+                const wf_f32x2 e = wf_f32x2{pp[r * PC + (hf ? 8 : 3)], pp[r * PC + (hf ? 8 : 3) + 1440]};
+                const wf_f32x2 a01 = wf_f32x2{ma.x, ma.y}, a23 = wf_f32x2{ma.z, ma.w}, b01 = wf_f32x2{mb.x, mb.y}, b23 = wf_f32x2{mb.z, mb.w};
+                wf_f32x2 m0, m1, m2, m3;  // (D.lo = S0[op_sel 0], D.hi = S1[op_sel 1])
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(m0) : "v"(a01), "v"(b01));
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(m1) : "v"(a01), "v"(b01));
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(m2) : "v"(a23), "v"(b23));
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(m3) : "v"(a23), "v"(b23));
+                if (hf == 0) {  // window columns d0 .. d4 = e, m0 .. m3 -> t0, t1, t2 of wino4_bt
+                    const wf_f32x2 a = m3 - 4.f * m1, b = m2 - 4.f * m0;
+                    t[r][0] = 4.f * e - 5.f * m1 + m3;
+                    t[r][1] = a + b;
+                    t[r][2] = a - b;
+                } else {  // d1 .. d5 = m0 .. m3, e -> t3, t4, t5
+                    const wf_f32x2 c = m3 - m1, f = m2 - m0;
+                    t[r][0] = c + 2.f * f;
+                    t[r][1] = c - 2.f * f;
+                    t[r][2] = 4.f * m0 - 5.f * m2 + e;
+                }
             }
-            float* vp = wsm + (kc & 1) * VS + ((tch & 1) * 32 + tj) * 4 + (tch >> 1);
+            wf_f32x2* vp = reinterpret_cast<wf_f32x2*>(wsm + (kc & 1) * VS + ((cpair & 1) * 32 + tj) * 4 + 2 * (cpair >> 1)) + (3 * hf) * 128;
 #pragma unroll
-            for (int jj = 0; jj < 6; ++jj) {
-                const float col[6] = {t[0][jj], t[1][jj], t[2][jj], t[3][jj], t[4][jj], t[5][jj]};
-                float o[6];
+            for (int jl = 0; jl < 3; ++jl) {
+                const wf_f32x2 col[6] = {t[0][jl], t[1][jl], t[2][jl], t[3][jl], t[4][jl], t[5][jl]};
+                wf_f32x2 o[6];
                 wino4_bt(col, o);
 #pragma unroll
-                for (int i6 = 0; i6 < 6; ++i6) vp[(i6 * 6 + jj) * 256] = sc * o[i6];
+                for (int i6 = 0; i6 < 6; ++i6) vp[(i6 * 6 + jl) * 128] = sc * o[i6];
             }
+        };
+        auto transform = [&](int bi, int kc, int g) __attribute__((always_inline)) {
+            if (hfw) transform_h(std::integral_constant<int, 1>{}, bi, kc, g);  // (wave-uniform)
+            else transform_h(std::integral_constant<int, 0>{}, bi, kc, g);
         };
         // prologue: chunks 0, 1, 2 on their way; 0 and 1 landed
         issue(0);
@@ -266,10 +299,17 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     const int half = lane >> 5, j = lane & 31;
     const int g = wave;
     wf_f32x16 acc[9];
-    const float4* uf4 = reinterpret_cast<const float4*>(uf);
-    float4 a[9];  // A operands, loaded one tick ahead and in place: a[q] is reloaded right behind the four MFMAs that consumed it
+    // A operands, loaded one tick ahead and in place: a[q] is reloaded right behind the four MFMAs that consumed it.  Buffer loads: the
+    // lane's part of the address is ONE VGPR, the (position, chunk) part a scalar offset -- no VALU address arithmetic in the wave that
+    // issues the MFMAs (a wave's own instructions are never hidden by its MFMAs: tools/issue_probe.hip)
+    float4 a[9];
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uf), (short)0, (int)(unsigned)((int64_t)36 * K * N * 4), 0x00020000);
+    const int voff_a = (half * N + n0 + j) * 16;
+    const unsigned stride_a = (unsigned)(2 * N) * 16u;  // bytes per (position, 8-channel chunk)
     auto a_at = [&](int q, int kc) __attribute__((always_inline)) {
-        return uf4[((((int64_t)(9 * g + q) << kc_log2) + kc) * 2 + half) * N + n0 + j];
+        typedef float a_f32x4 __attribute__((ext_vector_type(4)));
+        const a_f32x4 v = __builtin_bit_cast(a_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, voff_a, (int)((unsigned)(((9 * g + q) << kc_log2) + kc) * stride_a), 0));
+        return make_float4(v.x, v.y, v.z, v.w);
     };
     auto mfma_tick = [&](int stage, int next_kc) __attribute__((always_inline)) {
         const float4* vs4 = reinterpret_cast<const float4*>(wsm + stage * VS);
