@@ -11,7 +11,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // roles: 0 idle, 1 MFMA 32x32x2 only, 2 MFMA 16x16x4 only, 3 16 x v_fma_f32 (CH independent chains), 4 16 x v_pk_fma_f32 (CH chains),
 //        5 16 x ds_write_b32, 6 8 x v_fma + 8 x ds_write_b32 interleaved
-template <int ROLE_A, int ROLE_B, int CH>
+template <int ROLE_A, int ROLE_B, int CH, int PRIO_B = 0>
 __global__ __launch_bounds__(512, 1) void probe(unsigned long long* out, int iters, float seed) {
     __shared__ float lds[8192];
     const int wave = threadIdx.x >> 6;
@@ -27,6 +27,7 @@ __global__ __launch_bounds__(512, 1) void probe(unsigned long long* out, int ite
     for (int i = 0; i < 8; ++i) s[i] = seed * (i + 1) + threadIdx.x, p[i] = f32x2{seed * i, seed + i};
     float x = seed + (threadIdx.x & 31), y = seed - (threadIdx.x & 7);
     const unsigned laddr = (threadIdx.x & 255) * 4;
+    if (PRIO_B && wave >= 4) __builtin_amdgcn_s_setprio(3);  // (wave-uniform)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (role == 1) {
         for (int it = 0; it < iters; ++it) {
@@ -72,13 +73,13 @@ __global__ __launch_bounds__(512, 1) void probe(unsigned long long* out, int ite
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int RA, int RB, int CH>
+template <int RA, int RB, int CH, int PB = 0>
 static void run(const char* name, int per_iter_a, int per_iter_b) {
     unsigned long long* d;
     hipMalloc(&d, 4096);
     const int iters = 2000;
-    probe<RA, RB, CH><<<1, 512>>>(d, 10, 1.0f);
-    probe<RA, RB, CH><<<1, 512>>>(d, iters, 1.0f);
+    probe<RA, RB, CH, PB><<<1, 512>>>(d, 10, 1.0f);
+    probe<RA, RB, CH, PB><<<1, 512>>>(d, iters, 1.0f);
     unsigned long long h[8];
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     double a = 0, b = 0;
@@ -89,7 +90,6 @@ static void run(const char* name, int per_iter_a, int per_iter_b) {
 }
 
 int main() {
-    // (s_memtime counts at 100 MHz on this part: the probe reports in ITS units consistently; compare rows, and see the MFMA-only row for scale)
     run<1, 0, 4>("A: MFMA 32x32x2 only", 4, 0);
     run<2, 0, 4>("A: MFMA 16x16x4 only", 8, 0);
     run<3, 0, 4>("A: v_fma_f32, 4 chains", 16, 0);
@@ -103,6 +103,9 @@ int main() {
     run<1, 4, 8>("A: MFMA 32x32x2, B: v_pk_fma_f32 8 chains", 4, 16);
     run<2, 3, 8>("A: MFMA 16x16x4, B: v_fma_f32 8 chains", 8, 16);
     run<2, 4, 8>("A: MFMA 16x16x4, B: v_pk_fma_f32 8 chains", 8, 16);
+    run<1, 3, 8, 1>("A: MFMA 32x32x2, B: v_fma_f32 8 chains, s_setprio 3 in B", 4, 16);
+    run<1, 4, 8, 1>("A: MFMA 32x32x2, B: v_pk_fma_f32 8 chains, s_setprio 3 in B", 4, 16);
+    run<1, 6, 8, 1>("A: MFMA 32x32x2, B: v_fma + ds_write_b32, s_setprio 3 in B", 4, 16);
     run<1, 5, 4>("A: MFMA 32x32x2, B: ds_write_b32", 4, 16);
     run<1, 6, 8>("A: MFMA 32x32x2, B: v_fma + ds_write_b32 interleaved", 4, 16);
     run<2, 6, 8>("A: MFMA 16x16x4, B: v_fma + ds_write_b32 interleaved", 8, 16);
