@@ -242,7 +242,9 @@ class Coach:
             torch.cuda.synchronize()
             memset_guard(body, "capture_step: the step")
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread_local: with a process group alive, RCCL's watchdog thread queries events on its own; under the default
+            # "global" mode any such call from another thread invalidates a capture in progress)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_out = body()
         finally:
             self._side = eager_side
