@@ -54,4 +54,5 @@ echo winograd done
 timeout -k 10 200 python3 tools/cfg_selections.py $O/cfg_selections.txt > /dev/null 2>&1 || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/issue_probe.hip -o /tmp/issue_probe 2> /dev/null && /tmp/issue_probe > $O/issue_probe.txt 2>&1 || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/dma_probe.hip -o /tmp/dma_probe 2> /dev/null && /tmp/dma_probe > $O/dma_probe.txt 2>&1 || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/pk_probe.hip -o /tmp/pk_probe 2> /dev/null && /tmp/pk_probe > $O/pk_probe.txt 2>&1 || true
 echo extras done
