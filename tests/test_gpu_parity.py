@@ -1001,7 +1001,7 @@ def test_wino_gemm_edge_shapes_and_argument_errors():
                                          (4, 2, 128, 128, 16, 32), (4, 1, 192, 64, 8, 16),
                                          (11, 2, 512, 512, 16, 16), (11, 3, 64, 64, 16, 16), (11, 1, 128, 64, 32, 64), (12, 2, 256, 128, 32, 32),
                                          (8, 2, 32, 32, 32, 64), (8, 1, 64, 64, 16, 32), (8, 3, 128, 32, 48, 32), (8, 2, 64, 32, 32, 32), (8, 5, 32, 64, 64, 64),
-                                         (8, 2, 32, 128, 32, 32), (8, 1, 32, 32, 64, 96)])
+                                         (8, 2, 32, 128, 32, 32), (8, 1, 32, 32, 64, 96), (8, 1, 256, 32, 16, 64), (8, 2, 256, 64, 32, 32)])
 def test_modconv_winograd_form(m, b, k, n, h, w):
     """K1w / K1g: the Winograd F(4x4,3x3) forms of the same-resolution conv against float64 convolutions, every epilogue of w2e_modconv3x3
     -- plain, unmodulated, noise + bias + LeakyReLU, and the input-gradient pass (transposed + flipped pack) with the fused per-channel
