@@ -246,7 +246,59 @@ def self_launch(args):
     raise SystemExit(max(abs(rc) for rc in rcs))
 
 
-def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0, world=1, device=None):
+def rehearse(args):
+    """`--rehearse`: the control flow of an N-rank run of main() with NO GPU work, so that the launcher, the rendezvous, the collective
+    stop rule of stabilise(), the barriers, the MAX over ranks and the JSON relay have run at the world size a real node will use
+    before a real node sees them (a GPU box allows at most 6 processes on its card; this needs none).  The step is a stand-in: a
+    2 ms sleep whose length depends on the rank (so that the ranks would leave the stabilisation loop after different numbers of
+    steps if they decided alone) + the all-reduce of a LevelsMapper-sized bucket (3.15 M floats) of host memory over gloo."""
+    from where2edit_amd import dist as wd
+    rank, world, _ = wd.init_from_env(backend="gloo", timeout_s=120)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    bucket = torch.zeros(3_150_000)
+    calls = [0]
+
+    def step():
+        calls[0] += 1
+        time.sleep(0.002 * (1.0 + 0.5 * rank / max(world - 1, 1)) * (3.0 if calls[0] <= 2 + rank else 1.0))  # rank-dependent settling
+        bucket.fill_(float(rank + 1))
+        if world > 1:
+            torch.distributed.all_reduce(bucket)
+            bucket.div_(world)
+        return {"loss": bucket[0]}
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    n_stab, ok = stabilise(step, world=world, device="cpu", sync=lambda: None, max_seconds=10.0)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    want = sum(range(1, world + 1)) / world  # every rank's bucket holds the mean of (rank + 1)
+    if abs(float(last["loss"]) - want) > 1e-6:
+        raise SystemExit(f"rehearsal: the bucket holds {float(last['loss'])} after the all-reduce, expected {want}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal of the N-rank launcher (no GPU work, stand-in step): NOT a measurement", "value": None,
+                          "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "rehearsal": True, "steps_run_per_rank": calls[0], "stabilise_steps": n_stab, "stabilised": ok,
+                          "config": {"workload": "stand-in step: sleep + gloo all-reduce of a 12.6 MB host bucket", "dist_backend": "gloo"}}),
+              flush=True)
+
+
+def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0, world=1, device=None, sync=None):
     """Untimed full steps until the last `window` step times agree within `tol` ((max-min)/mean): a fresh box leaves its idle
     clocks, caches / allocator pools / lazily built packs settle.  Independent of --warmup, so the timed region starts at
     steady state whatever the caller asks for (round 1 lost 10 % of its headline to a 5-step warm-up).
@@ -254,12 +306,13 @@ def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0, world
     different numbers of steps would leave the last all-reduces of the slower ones without a partner): stop when every rank is
     stable, or when any rank has hit a limit."""
     times = []
+    sync = sync if sync is not None else torch.cuda.synchronize
     t_begin = time.perf_counter()
     while True:
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         step_fn()
-        torch.cuda.synchronize()
+        sync()
         times.append(time.perf_counter() - t0)
         last = times[-window:]
         stable = len(last) == window and (max(last) - min(last)) <= tol * (sum(last) / window)
@@ -272,14 +325,12 @@ def stabilise(step_fn, tol=0.02, window=5, max_steps=80, max_seconds=20.0, world
             return len(times), stable
 
 
-def measure_config5(args, rank, world, device, batch):
-    """BASELINE configs[4] on this rank's share of the images: 256^2 image -> e4e -> S codes -> features -> region-attention
-    net (mask + new codes) -> masked 1024^2 generator -> CLIP features (where2edit_amd.demo_pipeline.invert_and_edit).
-    Inference: every rank works on its own images, nothing is exchanged.  Random-init weights of the real architectures."""
+def build_config5(device, batch, rank):
+    """The modules and inputs of BASELINE configs[4] (random-init weights of the real architectures, seeded inputs): returns
+    (imgs [B,3,256,256], e4e, generator, clip_loss, region-attention net, text features, attention-text features)."""
     from where2edit_amd.attention_model import Generator
     from where2edit_amd.clip_loss import CLIPLoss
     from where2edit_amd.clip_vit import CLIP
-    from where2edit_amd.demo_pipeline import invert_and_edit
     from where2edit_amd.psp_encoders import Encoder4Editing
     from where2edit_amd.run_attention import FullSpaceMapperFEATClusterLinStyle_Net
     torch.manual_seed(0)
@@ -302,6 +353,15 @@ def measure_config5(args, rank, world, device, batch):
         ys, xs = (idx // 64).float() * 2 / 63 - 1, (idx % 64).float() * 2 / 63 - 1
         net.store_clusters(torch.cat([pts, xs.to(f.device)[:, None].repeat(1, 32), ys.to(f.device)[:, None].repeat(1, 32)], 1))
         del styles0, feats0, f
+    return imgs, e4e, g, clip, net, text, att
+
+
+def measure_config5(args, rank, world, device, batch):
+    """BASELINE configs[4] on this rank's share of the images: 256^2 image -> e4e -> S codes -> features -> region-attention
+    net (mask + new codes) -> masked 1024^2 generator -> CLIP features (where2edit_amd.demo_pipeline.invert_and_edit).
+    Inference: every rank works on its own images, nothing is exchanged.  Random-init weights of the real architectures."""
+    from where2edit_amd.demo_pipeline import invert_and_edit
+    imgs, e4e, g, clip, net, text, att = build_config5(device, batch, rank)
 
     def step():
         return invert_and_edit(imgs, e4e, g, clip, net, text, att, attention_layer=13)
@@ -404,15 +464,38 @@ def main():
                          "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8); 5 = the inference pipeline "
                          "e4e encode -> cluster-pooled mask -> mapper edit -> 1024^2 generator (show_demo/try_demo.py:93-157; "
                          "replicas only at N > 1, no collective)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch latents per GPU at every N (8 at N > 1: BASELINE configs[3] at N = 8).  strong: the "
+                         "GLOBAL batch is fixed at --global-batch (64 = configs[3]) whatever N; a GPU's shard of 64 / N latents runs as "
+                         "micro-batches of --batch (8) whose gradients are accumulated before the one all-reduce and the one optimizer "
+                         "step (Coach.accumulated_step) -- SURVEY 8(d) cfg4 asks for both curves")
+    ap.add_argument("--global-batch", type=int, default=64, help="--scaling strong: latents per step over all GPUs")
+    ap.add_argument("--no-n1-reference", action="store_true",
+                    help="N > 1: skip the K extra steps WITHOUT the gradient all-reduce that give the line its one-GPU figure at "
+                         "the same per-GPU batch (`n1_equal_batch`)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher rehearsal WITHOUT any GPU work (runs where there is no GPU, at any world size): the real control flow "
+                         "of an N-rank run -- self-launch or torchrun environment, gloo rendezvous, the collective stop rule of the "
+                         "stabilisation loop, warm-up, barriers, K timed steps, MAX over ranks, rank 0's one JSON line -- around a "
+                         "stand-in step (2 ms sleep + the all-reduce of a 12.6 MB bucket of host memory).  The line it prints says so "
+                         "and carries no value")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 4 if args.gpus == 1 else 8
+        args.batch = 4 if (args.gpus == 1 and args.scaling == "weak") else 8
+    if args.scaling == "strong":
+        if args.workload != 2:
+            raise SystemExit("--scaling strong is defined for the mapper training step (--workload 2)")
+        if args.global_batch % (args.gpus * args.batch):
+            raise SystemExit(f"--scaling strong: global batch {args.global_batch} is not a whole number of micro-batches of "
+                             f"{args.batch} on each of {args.gpus} GPUs")
     tune = sorted(k for k in os.environ if k.startswith("W2E_TUNE_"))
     if tune:  # the tuning aids can skip work or force slow tiles: never measure with them set
         raise SystemExit(f"bench.py refuses to run with tuning variables set: {', '.join(tune)}")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
+    if args.rehearse:
+        return rehearse(args)
     from where2edit_amd import _lib
     from where2edit_amd import dist as wd
     from where2edit_amd import profiling
@@ -428,8 +511,13 @@ def main():
     _lib.set_option("conv_precision", args.conv_precision)
     if args.workload == 5:
         return bench_config5(args, rank, world, device)
-    coach = build_coach(args.size, args.batch, device, world > 1, 'hip', args.workload)
-    w = synthetic_latents(coach.net.decoder, args.batch, rank)
+    strong = args.scaling == "strong"
+    per_gpu = args.global_batch // world if strong else args.batch  # latents this GPU processes per step
+    n_micro = per_gpu // args.batch                                  # ... as this many passes of --batch latents (1 unless strong)
+    coach = build_coach(args.size, args.batch, device, world > 1 or strong, 'hip', args.workload)
+    w_all = synthetic_latents(coach.net.decoder, per_gpu, rank)
+    chunks = list(w_all.split(args.batch))
+    w = chunks[0]
     mask = make_mask(coach, args.batch, args.size, rank, device, args.synthetic_mask) if args.workload == 3 else None
 
     def barrier():
@@ -437,12 +525,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    step_fn = lambda: coach.train_step(w, mask)  # noqa: E731
-    use_graph, graph_note = False, None
+    eager_fn = (lambda: coach.accumulated_step(chunks)) if strong else (lambda: coach.train_step(w, mask))  # noqa: E731
+    step_fn = eager_fn
+    use_graph, graph_note, graphed = False, None, None
     if args.graph != "off":
         try:  # (a callable mask -- the region-attention net's mask branch -- is captured between the two generator passes)
             graphed = coach.capture_step(w, mask, side_stream=args.side_stream)
-            step_fn = lambda: graphed(w, mask)  # noqa: E731
+            step_fn = (lambda: coach.accumulated_step(chunks, graphed)) if strong else (lambda: graphed(w, mask))  # noqa: E731
             use_graph = True
         except Exception as e:  # noqa: BLE001  (any capture failure: measure eagerly rather than not at all)
             if args.graph == "on":
@@ -465,7 +554,7 @@ def main():
         if timer is not None:
             timer.__enter__()
             for i in range(max(1, args.steps // args.timing_stride)):
-                coach.train_step(w, mask)
+                eager_fn()
                 sampled += 1
             barrier()
             timer.__exit__(None, None, None)
@@ -482,10 +571,34 @@ def main():
         dt = time.perf_counter() - t0
         if timer is not None:
             timer.__exit__(None, None, None)
+    n1_ref = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
+        if not args.no_n1_reference:
+            # The one-GPU figure this line's `value` has to be divided by for a scaling ratio: the SAME K steps at the SAME per-GPU
+            # batch, same process, same box, with the gradient all-reduce taken out -- i.e. what one GPU does when it is alone
+            # (GradBucket.all_reduce_mean is the step's only collective).  Every rank runs them; the slowest rank's time is used.
+            bucket_reduce, coach.bucket.all_reduce_mean = coach.bucket.all_reduce_mean, (lambda: None)
+            try:
+                for _ in range(3):
+                    step_fn()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_fn()
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+            finally:
+                coach.bucket.all_reduce_mean = bucket_reduce
+            t = torch.tensor([dt1, -dt1], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            n1_ref = {"value": per_gpu * args.steps / t[0].item(), "unit": "images/s", "ms_per_step": 1e3 * t[0].item() / args.steps,
+                      "fastest_rank_ms_per_step": 1e3 * -t[1].item() / args.steps, "per_gpu_batch": per_gpu,
+                      "what": f"ONE GPU's rate on this step at {per_gpu} latents per GPU: the same {args.steps} steps in the same processes "
+                              "right after the timed region with the gradient all-reduce removed (slowest rank); "
+                              "value / (n_gpus x this) = the parallel efficiency at equal per-GPU work"}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -493,25 +606,35 @@ def main():
     loss = float(last["loss"])
     if not (loss == loss):
         raise SystemExit("loss is NaN")
-    global_batch = args.batch * world
+    global_batch = per_gpu * world
     value = global_batch * args.steps / dt
     out = {
         "metric": "1024^2 edited images/sec per mapper step" if args.size == 1024 else f"{args.size}^2 edited images/sec per mapper step",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.conv_precision, "data": "synthetic",
-        "config": {"workload": ((f"BASELINE configs[1]: " if (world == 1 and args.batch == 4 and args.size == 1024) else
+        "config": {"workload": ((f"BASELINE configs[1]: " if (world == 1 and per_gpu == 4 and args.size == 1024) else
                                  f"BASELINE configs[3] (FFHQ-1024 mapper training, global batch {global_batch}, data-parallel over {world} GPUs, "
-                                 f"RCCL all-reduce of the mapper gradients): " if (world > 1 and args.batch == 8 and args.size == 1024) else "") +
-                                f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), batch {args.batch}/GPU, "
-                                f"LevelsMapper, Ranger, id_lambda=0") if args.workload == 2 else
+                                 f"RCCL all-reduce of the mapper gradients): " if (global_batch == 64 and args.size == 1024) else
+                                 f"the per-GPU workload of BASELINE configs[3] on {world} GPU(s) (weak scaling towards 64 latents on 8): "
+                                 if (per_gpu == 8 and args.size == 1024) else "") +
+                                f"FFHQ-{args.size} StyleGAN2 + clip_loss mapper step (coach.py:79-92), {per_gpu} latents/GPU" +
+                                (f" as {n_micro} micro-batches of {args.batch} with accumulated gradients" if n_micro > 1 else "") +
+                                f", LevelsMapper, Ranger, id_lambda=0" +
+                                (f"; scaling reference = `n1_equal_batch` of this line (one GPU at {per_gpu} latents, no collective), "
+                                 f"same workload as `bench.py --gpus 1 --batch {per_gpu}` / `n1_b8` of the N=1 line" if (world > 1 and not strong) else "") +
+                                (f"; strong scaling: global batch {global_batch} at every N, the N=1 point is `bench.py --gpus 1 --scaling strong`"
+                                 if strong else "")) if args.workload == 2 else
                                (f"FFHQ-{args.size} mapper step with the region-attention mask (cluster-pooled, thresholded, blurred: run_attention.py:754-884"
                                 f"{' -- synthetic U(0,1) mask' if callable(mask) is False else ''}) blended at layer 13 (attention_model.py) "
                                 f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
-                   "global_batch": global_batch,
+                   "global_batch": global_batch, "per_gpu_batch": per_gpu, "micro_batch": args.batch, "micro_batches_per_step": n_micro,
                    "parallelism": f"dp{world}", "conv_precision": args.conv_precision, "final_loss": loss,
                    "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "mask_mean": (float(mask.last.mean()) if hasattr(mask, "last") else None), "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None},
     }
+    if n1_ref is not None:
+        out["n1_equal_batch"] = n1_ref
+        out["parallel_efficiency_vs_n1_equal_batch"] = value / (world * n1_ref["value"])
     if timer is not None:
         s = timer.summary()
         # every 3x3 modulated conv of the step: the direct MFMA kernels ("modconv3x3") and the Winograd-form layers
@@ -568,7 +691,7 @@ def main():
         if args.size == 1024:
             stack_tflops = 3 * G_FWD_GFLOP_1024 * 1e9 * global_batch * args.steps / dt / 1e12 / world
             out["stack_mfma_frac_of_step"] = stack_tflops / FP32_MFMA_PEAK_TFLOPS
-    if world == 1 and args.conv_precision == "f32" and not args.no_preview:
+    if world == 1 and not strong and args.conv_precision == "f32" and not args.no_preview:
         # the same K steps once more with the opt-in conv precision (w2e_set_option):
         # reported beside the headline, never as `value`
         _lib.set_option("conv_precision", "bf16x3")
@@ -585,7 +708,7 @@ def main():
                                  "dtype": "bf16x3", "final_loss": float(last2["loss"]),
                                  "note": "opt-in --conv-precision bf16x3: each fp32 product of the 3x3 convs as three bf16 MFMA products "
                                          "(all parity tests pass with it; DESIGN.md section 7); not the headline"}
-    if world == 1 and args.workload == 2 and args.size == 1024 and args.batch == 4 and args.conv_precision == "f32" and not args.no_n1_b8:
+    if world == 1 and not strong and args.workload == 2 and args.size == 1024 and args.batch == 4 and args.conv_precision == "f32" and not args.no_n1_b8:
         # the same step at 8 latents per GPU = the per-GPU workload of `--gpus N > 1` (BASELINE configs[3]), so that the driver's
         # N-GPU values have a 1-GPU figure at equal per-GPU batch beside the configs[1] headline.  Never `value`.
         del coach
@@ -612,7 +735,7 @@ def main():
                                     "`bench.py --gpus N` for N > 1); same as `bench.py --batch 8`"}
         del coach8
         coach = None
-    if world == 1 and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config3:
+    if world == 1 and not strong and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config3:
         # BASELINE configs[2] in the same run, so that a driver-run line exists for it: region-attention mask (the real one) +
         # clip_loss + id_loss (IR-SE50 on the conv engine), batch 8.  Reported beside the headline, never as `value`.
         coach = None
@@ -641,7 +764,7 @@ def main():
                           "workload": "BASELINE configs[2]: FFHQ-1024 mapper step with the region-attention mask (cluster-pooled, "
                                       "thresholded, blurred; run_attention.py:754-884) blended at layer 13 + clip_loss + id_loss "
                                       "(IR-SE50), batch 8, 1 GPU; same as `bench.py --workload 3 --batch 8`"}
-    if world == 1 and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config5:
+    if world == 1 and not strong and args.workload == 2 and args.size == 1024 and args.conv_precision == "f32" and not args.no_config5:
         # BASELINE configs[4] (invert-and-edit inference) at ONE GPU's share of its 32 images over 8 GPUs, in the same run so that a
         # driver-run figure exists for it.  Reported beside the headline, never as `value`.
         coach = coach3 = None

@@ -47,6 +47,7 @@ def pytest_terminal_summary(terminalreporter):
     except ImportError:
         return
     if GRAD_ERRORS:
-        terminalreporter.write_sep("-", "end-to-end gradient parity: max-norm relative error, cosine")
-        for what, e, cos in GRAD_ERRORS:
-            terminalreporter.write_line(f"{e:10.3e}  {cos:.7f}  {what}")
+        terminalreporter.write_sep("-", "end-to-end gradient parity: max-norm relative error, cosine, tolerance held to")
+        for what, e, cos, *tol in GRAD_ERRORS:
+            held = f"(<= {tol[0]:.0e})" if tol and tol[0] is not None else "          "
+            terminalreporter.write_line(f"{e:10.3e}  {cos:.7f}  {held}  {what}")

@@ -63,6 +63,10 @@ def test_version_and_argument_errors_do_not_need_a_gpu(lib):
     # argument validation happens before any HIP call: a null tensor is refused with a message
     rc = lib.w2e_clip_preproc_fwd(None, None, ctypes.c_int64(1), 1024, None)
     assert rc != 0 and b"null" in lib.w2e_last_error()
+    # w2e_gemm_pk: an output pitch below n would make rows of a slab overlap -- refused before any launch
+    lib.w2e_gemm_pk.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+    rc = lib.w2e_gemm_pk(ctypes.c_void_p(64), ctypes.c_void_p(64), ctypes.c_void_p(64), 32, 128, 64, 32, 128, 96, 1, None)
+    assert rc != 0 and b"ldc 96 < n 128" in lib.w2e_last_error()
     lib.w2e_upfirdn2d.argtypes = None
 
 
@@ -190,6 +194,12 @@ def test_styleclip_mapper_surface(tmp_path):
     torch.save({"state_dict": net.state_dict(), "opts": vars(net.opts)}, full)
     net2 = StyleCLIPMapper(_opts(checkpoint_path=str(full)))
     assert set(get_keys(torch.load(full), "mapper")) == set(net2.mapper.state_dict())
+    # built the reference's way (nothing frozen by the caller): the wrapper freezes exactly the conv weights the kernels cannot
+    # differentiate; every other decoder parameter keeps requires_grad (the reference leaves all of them trainable, coach.py:91)
+    from where2edit_amd.stylegan2 import ModulatedConv2d
+    conv_w = {id(m.weight) for m in net.decoder.modules() if isinstance(m, ModulatedConv2d)}
+    assert conv_w and all(p.requires_grad == (id(p) not in conv_w) for p in net.decoder.parameters())
+    assert all(p.requires_grad for p in net.mapper.parameters())
     with pytest.raises(Exception, match="not a valid mapper"):
         StyleCLIPMapper(_opts(mapper_type="Nope"))
     for kw, cls in ((dict(mapper_type="SingleMapper"), "SingleMapper"), (dict(work_in_stylespace=True), "WithoutToRGBStyleSpaceMapper")):
@@ -280,3 +290,42 @@ def test_bench_refuses_tuning_variables():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=dict(os.environ, W2E_TUNE_SKIP="2"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "W2E_TUNE_SKIP" in (r.stderr + r.stdout)
+
+
+def test_fused_winograd_kernel_keeps_its_hand_counted_waits():
+    """The fused Winograd kernel's transform waves stage their patches with inline-asm `buffer_load_dwordx4 ... lds` and wait for them
+    with HAND-WRITTEN `s_waitcnt vmcnt(6)` (csrc/winograd.hip: six DMA instructions per wave and chunk, the newest chunk may fly).
+    That is right only while (i) the compiler issues no VMEM load of its own inside those waves' tick loop (its wait would be counted
+    on the same in-order counter) and (ii) it merges no vmcnt into the waits it inserts there.  A compiler / ROCm change that breaks
+    either would still pass most numeric tests by luck of timing -- so the ISA is checked at build time: every kernel variant is
+    compiled to assembly here and the transform-wave region (from the first LDS-DMA instruction to the end of the kernel) must
+    contain, for the variants without the fused dot, no other VMEM load at all and no vmcnt wait except the two the source writes."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "where2edit_amd", "csrc", "winograd.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "wino.s")
+        r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
+                            "--cuda-device-only", "-o", out, src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        text = open(out).read()
+    kernels = re.findall(r"^(_ZN3w2e19wino4_fused3_kernelILi(\d)ELb(\d)ELi(\d+)EE\w+):[^\n]*\n(.*?)^\s*\.size\s+\1,", text, flags=re.S | re.M)
+    assert len(kernels) == 8, [k[0] for k in kernels]  # 4 epilogues x 2 block shapes
+    for name, act, dot, txn, body in kernels:
+        lines = [ln.strip() for ln in body.splitlines()]
+        first = next(i for i, ln in enumerate(lines) if re.match(r"buffer_load_dwordx4 .* lds$", ln))
+        region = lines[first:]
+        dma = [ln for ln in region if re.match(r"buffer_load_dwordx4 .* lds$", ln)]
+        assert dma and len(dma) % 6 == 0, (name, len(dma))  # whole groups of six per issue site
+        assert not any(re.match(r"buffer_load_dwordx4 .* lds$", ln) for ln in lines[:first])  # (the matrix waves issue none)
+        region = [ln.split(";")[0].strip() for ln in region]
+        waits = [ln for ln in region if ln.startswith("s_waitcnt") and "vmcnt" in ln]
+        assert "s_waitcnt vmcnt(6)" in waits, (name, waits)
+        if dot == "0":
+            other_loads = [ln for ln in region if re.match(r"(global_load|buffer_load|flat_load|scratch_load)", ln) and not ln.endswith(" lds")]
+            assert not other_loads, (name, other_loads[:4])
+            assert set(waits) <= {"s_waitcnt vmcnt(6)", "s_waitcnt vmcnt(0)"}, (name, sorted(set(waits)))
+        # (a spill is a VMEM access on the same counter: none in the transform waves of any variant; the matrix waves of the PReLU and
+        # fused-dot variants spill one or two 8-byte pairs at 255 VGPRs -- outside this region, waited for by the compiler itself)
+        assert not any("scratch_" in ln for ln in region), name

@@ -134,3 +134,51 @@ def test_gather_layer_and_infonce_over_two_ranks(tmp_path):
         assert torch.equal(res[r]["gathered"], img.detach())
         assert_close(res[r]["loss"], full.detach(), 1e-6, "InfoNCE over the gathered batch")
         assert_close(res[r]["grad"], img.grad[r * 3:(r + 1) * 3], 1e-5, "this rank's rows of the full-batch gradient")
+
+
+def _run_bench(argv, env=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable] + argv, cwd=root, env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # (gloo's C++ side prints its own
+    #                                                                connection notes to stdout under torchrun; RCCL runs have none)
+    return r, lines, (json.loads(lines[0]) if len(lines) == 1 and lines[0].startswith("{") else None)
+
+
+def test_bench_launcher_rehearsal_at_world_8():
+    """`bench.py --gpus 8 --rehearse`: the parent starts 8 ranks itself (self_launch), they rendezvous over gloo, leave the
+    stabilisation loop TOGETHER (the stand-in step settles after a rank-dependent number of steps: alone, the ranks would stop at
+    different counts and strand each other's all-reduces), run warm-up + K steps between barriers, reduce the time with MAX, and rank
+    0's single JSON line comes back through the parent's stdout.  No GPU work anywhere (a GPU box allows 6 processes on its card)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r, lines, out = _run_bench([os.path.join(root, "bench.py"), "--gpus", "8", "--rehearse", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None, (lines, r.stderr[-1000:])  # exactly one line on stdout, and it is JSON
+    assert out["n_gpus"] == 8 and out["rehearsal"] is True and out["value"] is None and out["steps"] == 3
+    assert out["steps_run_per_rank"] == out["stabilise_steps"] + 1 + 3  # every rank ran the same number of collectives
+
+
+def test_bench_rehearsal_under_the_drivers_torchrun_command():
+    """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment and
+    bench.py must NOT start ranks of its own."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r, lines, out = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse",
+                                "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None and out["n_gpus"] == 2 and out["rehearsal"] is True, (lines, r.stderr[-1000:])
+
+
+def test_bench_strong_scaling_arguments_are_checked_before_any_gpu_work():
+    """--scaling strong: a global batch that is not a whole number of micro-batches per GPU is refused by the argument check (no GPU,
+    no library needed)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r, _, _ = _run_bench([os.path.join(root, "bench.py"), "--gpus", "3", "--scaling", "strong", "--global-batch", "64"])
+    assert r.returncode != 0 and "not a whole number of micro-batches" in r.stderr
+    r, _, _ = _run_bench([os.path.join(root, "bench.py"), "--scaling", "strong", "--workload", "5"])
+    assert r.returncode != 0 and "--scaling strong is defined for the mapper training step" in r.stderr

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """RCCL self-test on ONE GPU: a world-size-1 nccl process group (its watchdog thread included), the data-parallel Coach with the
 flat gradient bucket, eager steps, then the hipGraph-captured step with the all-reduce after each replay -- what
-`bench.py --gpus N` runs per rank.  usage: dp_rccl_selftest.py [size batch]"""
+`bench.py --gpus N` runs per rank; with a third argument `pipeline`, also BASELINE configs[4]'s inference pipeline captured and replayed
+while the group is alive (what `bench.py --workload 5 --gpus N` does per rank).  usage: dp_rccl_selftest.py [size batch [pipeline]]"""
 import os
 import sys
 
@@ -33,4 +34,18 @@ torch.cuda.synchronize()
 loss = float(d["loss"])
 assert loss == loss, "NaN loss after graph replays"
 print("RCCL world-1 DP graphed step ok, loss", loss, flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "pipeline":
+    from where2edit_amd.demo_pipeline import capture_invert_and_edit, invert_and_edit  # noqa: E402
+    del coach, step
+    torch.cuda.empty_cache()
+    imgs, e4e, g, clip, net, text, att = bench.build_config5("cuda:0", 1, 0)
+    eager = invert_and_edit(imgs, e4e, g, clip, net, text, att, attention_layer=13)
+    run = capture_invert_and_edit(torch.zeros_like(imgs), e4e, g, clip, net, torch.zeros_like(text), torch.zeros_like(att), attention_layer=13)
+    dist.barrier()
+    rep = run(imgs, text, att)
+    torch.cuda.synchronize()
+    for key in ("img_orig", "mask", "img_gen", "features_gen"):
+        err = float((rep[key] - eager[key]).abs().max() / eager[key].abs().max().clamp_min(1e-30))
+        assert err <= 1e-5, (key, err)
+    print("RCCL world-1 pipeline captured with the group alive and replayed ok", flush=True)
 dist.destroy_process_group()

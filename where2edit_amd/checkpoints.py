@@ -52,7 +52,10 @@ def load_clusters(path):
 def load_generator_weights(generator, path):
     """run_attention.py:982-986 / styleclip_mapper.py:44-46: ckpt['g_ema'], strict=False."""
     ckpt = torch.load(path, map_location="cpu")
-    return generator.load_state_dict(ckpt["g_ema"], strict=False)
+    res = generator.load_state_dict(ckpt["g_ema"], strict=False)
+    from .stylegan2 import freeze_conv_weights  # a loaded generator is a frozen decoder on this path (no conv-weight gradient
+    freeze_conv_weights(generator)              # kernels: stylegan2._trainable_weight); every other parameter keeps its flag
+    return res
 
 
 def save_coach_checkpoint(net, opts, path):

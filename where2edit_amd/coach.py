@@ -158,7 +158,8 @@ class Coach:
             loss = loss_id * self.opts.id_lambda
         s_space = getattr(self.opts, "work_in_stylespace", False)
         if self.opts.clip_lambda > 0 and self.opts.latent_l2_lambda > 0 and not s_space and torch.is_tensor(w_hat) and w_hat.is_cuda \
-                and w_hat.dtype == torch.float32 and FUSED_LOSS_TAIL:
+                and w_hat.dtype == torch.float32 and torch.is_tensor(w) and w.shape == w_hat.shape and w.dtype == w_hat.dtype \
+                and w.device == w_hat.device and FUSED_LOSS_TAIL:  # (any other pairing: the stock composition below, as the reference)
             # the clip and latent-L2 terms and their weighted sum as ONE launch (vit_hip.step_loss; backward: one more) instead of the
             # mean / mse_loss / mul / add chain and its autograd mirror
             from . import vit_hip
@@ -197,6 +198,44 @@ class Coach:
         self.global_step += 1
         return loss_dict
 
+    def accumulated_step(self, chunks, step=None):
+        """One mapper step on a shard that is processed as `len(chunks)` EQUAL micro-batches (bench.py --scaling strong: global batch
+        64 fixed, so one GPU's shard of 64 / N latents runs as micro-batches of 8 -- a single pass over 64 latents would put the
+        32 @ 1024^2 activations of the merged [w; w_hat] pass past the 4 GB one buffer descriptor covers and 32-bit element counts).
+        The loss terms are per-sample means (coach.py:223-245), so the gradient of the shard's mean loss is the mean of the
+        micro-batches' gradients: they are summed with weight 1/len(chunks) in an fp32 accumulator the size of the bucket, written
+        back, then ONE all-reduce and ONE optimizer step -- the same update as the unsplit step up to summation order.
+        `step`: a function from Coach.capture_step captured on a tensor of a chunk's shape (replayed with finish=False); None: eager.
+        Needs the flat gradient bucket (Coach(..., data_parallel=True); at world size 1 its all-reduce is skipped)."""
+        if self.bucket is None:
+            raise RuntimeError("accumulated_step needs the flat gradient bucket: build the Coach with data_parallel=True")
+        n = len(chunks)
+        if n == 1:
+            return step(chunks[0]) if step is not None else self.train_step(chunks[0])
+        if getattr(self, "_acc", None) is None:
+            self._acc = torch.zeros_like(self.bucket.flat)
+        self._acc.zero_()
+        sums = {}
+        for c in chunks:
+            if c.shape != chunks[0].shape:
+                raise ValueError("accumulated_step: micro-batches must have equal shapes (the mean of means is the mean only then)")
+            if step is not None:
+                d = step(c, finish=False)
+            else:
+                self.bucket.zero()
+                x, x_hat, w_hat = self.forward_pair(c)
+                loss, d = self.calc_loss(c, x, w_hat, x_hat)
+                loss.backward()
+            self._acc.add_(self.bucket.flat, alpha=1.0 / n)
+            for k_, v in d.items():  # (a graphed step returns the SAME static tensors every replay: fold them in now)
+                if torch.is_tensor(v):
+                    sums[k_] = v.detach() / n if k_ not in sums else sums[k_] + v.detach() / n
+        self.bucket.flat.copy_(self._acc)
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        self.global_step += 1
+        return sums
+
     # ---- the fixed-shape step as ONE hipGraph launch -------------------------------------------------------------
     def capture_step(self, w, mask=None, warmup=3, side_stream=False):
         """Capture zero-grad + forward_pair + calc_loss + backward for inputs of w's shape into a hipGraph (about 330
@@ -233,24 +272,14 @@ class Coach:
                 loss.backward()
                 return loss_dict
 
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    body()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            memset_guard(body, "capture_step: the step")
-            graph = torch.cuda.CUDAGraph()
-            # (thread_local: with a process group alive, RCCL's watchdog thread queries events on its own; under the default
-            # "global" mode any such call from another thread invalidates a capture in progress)
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                static_out = body()
+            graph, static_out = capture_graph(body, "capture_step: the step", self.device, warmup)
         finally:
             self._side = eager_side
         static_grads = [p.grad for p in params]
 
-        def step(w_new, mask_new=None):
+        def step(w_new, mask_new=None, finish=True):
+            """`finish=False`: replay only -- the gradients are left in the mapper's .grad (the bucket), no all-reduce, no optimizer
+            step (Coach.accumulated_step sums several such replays before it finishes the step once)."""
             if s_space:
                 for dst, src in zip(static_w, w_new):
                     dst.copy_(src)
@@ -259,11 +288,13 @@ class Coach:
             if static_mask is not None and mask_new is not None and not callable(static_mask):
                 static_mask.copy_(mask_new)
             graph.replay()
-            if self.bucket is not None:
-                self.bucket.all_reduce_mean()
-            else:  # an eager step in between (optimizer.zero_grad()) may have detached them
+            if self.bucket is None:  # an eager step in between (optimizer.zero_grad()) may have detached them
                 for p, g in zip(params, static_grads):
                     p.grad = g
+            if not finish:
+                return static_out
+            if self.bucket is not None:
+                self.bucket.all_reduce_mean()
             self.optimizer.step()
             self.global_step += 1
             return static_out
@@ -303,6 +334,28 @@ class Coach:
         """coach.py:163-172,267-272: {'state_dict': net.state_dict(), 'opts': vars(opts)}."""
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save({"state_dict": self.net.state_dict(), "opts": {k: v for k, v in vars(self.opts).items()}}, path)
+
+
+def capture_graph(body, what, device, warmup=3):
+    """The one way this package turns a fixed-shape, stream-ordered `body()` into a hipGraph (Coach.capture_step and
+    demo_pipeline.capture_invert_and_edit both come here): `warmup` eager runs on a side stream (they build every lazily cached
+    pack and opt the large-LDS kernels in on this device), the memset check below, then the capture.  Returns (graph, body's
+    return value inside the capture = the static outputs).
+    capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events on its own; under the
+    default "global" mode any such call from another thread invalidates a capture in progress (seen with bench.py --gpus N;
+    `bench.py --workload 5 --gpus N` keeps a group alive around the pipeline's capture in the same way)."""
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    memset_guard(body, what)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        out = body()
+    return graph, out
 
 
 def memset_guard(body, what):

@@ -159,6 +159,7 @@ int w2e_gemm_pk(const float* a_packed, const float* b_packed, float* c, int m, i
                 int splits, void* stream) {
     W2E_REQUIRE(a_packed && b_packed && c, "gemm_pk: null tensor");
     W2E_REQUIRE(m >= 0 && n > 0 && k > 0 && (k & 7) == 0, "gemm_pk: bad dims (K %% 8 == 0)");
+    W2E_REQUIRE(ldc >= n, "gemm_pk: ldc %d < n %d (rows of a slab would overlap)", ldc, n);
     W2E_REQUIRE(m_padded >= m && (m_padded & 31) == 0 && n_padded >= n && (n_padded & 63) == 0, "gemm_pk: m_padded %% 32 == 0, n_padded %% 64 == 0");
     W2E_REQUIRE((((uintptr_t)a_packed | (uintptr_t)b_packed) & 15) == 0, "gemm_pk: operands must be 16-byte aligned");
     W2E_REQUIRE((int64_t)(k >> 2) * m_padded * 16 < ((int64_t)1 << 32) - 64 && (int64_t)(k >> 2) * n_padded * 16 < ((int64_t)1 << 32) - 64, "gemm_pk: an operand exceeds 4 GB");

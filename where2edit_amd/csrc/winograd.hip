@@ -94,6 +94,13 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     constexpr int PQ = 8 * PR * QR;       // quads of one patch chunk (1440 for both shapes)
     static_assert(PR * PC == 720 && PQ <= 24 * 64, "patch geometry");
     constexpr int PS = 24 * 64 * 4;       // floats of one ring stage: 24 wave-instructions x 64 lanes x 16 B (>= PQ quads)
+    // LDS byte map (the launch passes the same sum as its dynamic size): V 0 .. 73 728, ring .. 147 456, tables .. 151 936.  The ring
+    // starts ABOVE 64 KB: the M0 base of `buffer_load ... lds` must carry byte offsets up to 147 455, which gfx950 (160 KB of LDS per
+    // CU) does and earlier parts with a 16-bit field do not -- an ISA change here has to fail the build, not the numbers.
+    static_assert(2 * VS * 4 == 73728 && (2 * VS + 3 * PS) * 4 == 147456, "fused Winograd kernel: LDS map of the V stages and the DMA ring");
+    static_assert((2 * VS + 3 * PS + 512 + 608) * 4 <= 160 * 1024, "fused Winograd kernel: more LDS than a gfx950 CU has");
+    static_assert((2 * VS + 3 * PS) * 4 < (1 << 18), "fused Winograd kernel: DMA ring offsets beyond M0's 18-bit LDS address");
+    static_assert(6 * 4 == 24 && 24 * 64 >= PQ, "fused Winograd kernel: 4 transform waves x 6 DMA instructions must cover a patch chunk");
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // V[2][VS], ring[3][PS], in_scale table [2][256]
     float* const mbuf = wsm;
     float* const ring = wsm + 2 * VS;

@@ -68,18 +68,8 @@ def capture_invert_and_edit(images, e4e, g_ema, clip_loss, mapper, text_features
     def body():
         return invert_and_edit(static[0], e4e, g_ema, clip_loss, mapper, static[1], static[2], **kw)
 
-    side = torch.cuda.Stream(device=images.device)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(warmup):
-            body()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    from .coach import memset_guard
-    memset_guard(body, "capture_invert_and_edit: the pipeline")
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = body()
+    from .coach import capture_graph  # (warm-up, memset check, thread-local capture: the same helper as Coach.capture_step)
+    graph, out = capture_graph(body, "capture_invert_and_edit: the pipeline", images.device, warmup)
 
     def run(images_new, text_new, attention_text_new):
         static[0].copy_(images_new), static[1].copy_(text_new), static[2].copy_(attention_text_new)

@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from . import latent_mappers
-from .stylegan2 import Generator
+from .stylegan2 import Generator, freeze_conv_weights
 
 
 def get_keys(d, name):
@@ -23,6 +23,12 @@ class StyleCLIPMapper(nn.Module):
         self.decoder = Generator(self.opts.stylegan_size, 512, 8)
         self.face_pool = torch.nn.AdaptiveAvgPool2d((256, 256))
         self.load_weights()
+        # The reference leaves requires_grad=True on the decoder and never optimises it (coach.py:174-180: net.mapper only), so
+        # its conv-weight gradients are computed and thrown away.  The HIP conv kernels compute none and refuse a weight that asks
+        # for one (stylegan2._trainable_weight) -- so a wrapper built the reference's way (parameters trainable by default, only
+        # the mapper handed to the optimizer) is made to work by freezing exactly those weights here; everything else of the
+        # decoder (biases, noise strengths, modulation affines, the constant input) keeps its flag and its gradient.
+        freeze_conv_weights(self.decoder)
 
     def set_mapper(self):
         if self.opts.work_in_stylespace:

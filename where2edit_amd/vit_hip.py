@@ -304,7 +304,7 @@ _PK_SPLITS = {}
 def _gemm_pk(a_packed, m, mpad, wpk):
     """[S, m, n] slabs = A x W^T on w2e_gemm_pk: both operands K-quad-major, one independent wave per (32 rows, 64 columns, K slice)."""
     wp, n, k, npad = wpk
-    key = (m, n, k)
+    key = (m, n, k, a_packed.device.index)  # (the plan depends on the CU count of the device the launch goes to)
     if key not in _PK_SPLITS:
         from . import _lib
         _PK_SPLITS[key] = _lib.load().w2e_gemm_pk_splits(m, n, k)
@@ -454,6 +454,7 @@ def clip_logits(feat, text_feat, logit_scale, similarity=False):
 def clip_logits_ok(feat, text_feat, logit_scale):
     """The fused tail applies when only the image features carry a gradient (the path's case) and everything is fp32 on the GPU."""
     return (feat.is_cuda and feat.dtype == torch.float32 and feat.ndim == 2 and text_feat.ndim == 2 and not text_feat.requires_grad
+            and feat.shape[1] == text_feat.shape[1] and text_feat.is_cuda and text_feat.dtype == torch.float32
             and not logit_scale.requires_grad)
 
 
@@ -464,6 +465,10 @@ class _StepLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sim, w_hat, w, clip_lambda, l2_lambda):
+        if w.shape != w_hat.shape or w.dtype != w_hat.dtype or w.device != w_hat.device:
+            # (the kernel walks both with w_hat's element count; nn.MSELoss would broadcast or raise here -- never read past `w`)
+            raise ValueError(f"step_loss: w {tuple(w.shape)} {w.dtype} {w.device} and w_hat {tuple(w_hat.shape)} {w_hat.dtype} "
+                             f"{w_hat.device} must have the same shape, dtype and device")
         sim, w_hat, w = _c(sim), _c(w_hat), _c(w.detach())
         out = torch.empty(3, device=w_hat.device, dtype=torch.float32)
         call("w2e_step_loss_fwd", ptr(sim), sim.numel(), ptr(w_hat), ptr(w), w_hat.numel(), float(clip_lambda), float(l2_lambda),
