@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
                                                               int n_blocks, const float* __restrict__ noise,
                                                               const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                               const float* __restrict__ slope, const float* __restrict__ dot_with,
-                                                              float* __restrict__ dot_partial, int skip) {
+                                                              float* __restrict__ dot_partial, int skip, int xmap) {
 #ifndef W2E_TUNING
     skip = 0;  // (tuning builds only: bit 0 no DMA after the prologue's, 1 no transform, 2 no MFMAs, 3 no output rounds)
 #endif
@@ -112,7 +112,19 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx_n = W / BWP, by_n = H / BHP, per_img = bx_n * by_n;
     const int KC = 1 << kc_log2;
-    const int count = (n_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Which blocks this workgroup loops over.  xmap = 0: block = blockIdx.x + i * gridDim.x -- at any moment the resident workgroups
+    // cover gridDim.x CONSECUTIVE blocks, but consecutive workgroup ids are dealt round-robin to the 8 XCDs, so every horizontal
+    // neighbour of a block is worked on by ANOTHER XCD: the 16-byte column halo on either side of a patch row lies in the neighbour's
+    // 128-byte lines, which each XCD's own L2 then fetches through the fabric a second time (profiles/r05_fetch_calibration.txt:
+    // a 288-byte row costs 4 lines of traffic).  xmap = 1: XCD j (= blockIdx.x & 7) owns the contiguous eighth [j n/8, (j+1) n/8)
+    // of the launch's blocks and its gridDim.x / 8 workgroups sweep it front to back -- horizontal neighbours run at the same time
+    // on the SAME XCD and share the halo lines in its L2; the row halo between consecutive sweeps of an XCD is re-read from L2 too.
+    // (The host sets xmap only when n_blocks and gridDim.x are multiples of 8 and every workgroup gets at least one block.)
+    const int xper = (int)gridDim.x >> 3;
+    const int xlo = xmap ? (n_blocks >> 3) * ((int)blockIdx.x & 7) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int xstep = xmap ? xper : (int)gridDim.x;
+    const int xend = xmap ? (n_blocks >> 3) * (((int)blockIdx.x & 7) + 1) : n_blocks;
+    const int count = (xend - xlo + xstep - 1) / xstep;
     const int total = count << kc_log2;
     const int n0 = blockIdx.y * 32;
     const int oj = tid & 31, on16 = tid >> 5;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         unsigned voff[6];  // byte offsets inside the image (b) of the block being ISSUED, or the out-of-range marker
         int voff_blk = -1;
         auto set_voff = [&](int bi) __attribute__((always_inline)) {
-            const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+            const int blk = xlo + bi * xstep;
             const int b = blk / per_img, rem = blk - b * per_img;
             const int by = rem / bx_n, bx = rem - by * bx_n;
             (void)b;
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         auto issue = [&](int g) __attribute__((always_inline)) {  // DMA of global chunk g into ring stage g % 3
             const int bi = g >> kc_log2, kc = g & (KC - 1);
             if (bi != voff_blk) set_voff(bi), voff_blk = bi;
-            const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+            const int blk = xlo + bi * xstep;
             const int b = blk / per_img;
             const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(b * K + kc * 8) * plane_bytes));
             const unsigned stage_b = lds_ring + (unsigned)(g % 3) * (unsigned)(PS * 4) + (unsigned)(tw * 6) * 1024u;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
                 else __builtin_amdgcn_s_waitcnt(0x0F70);
                 __syncthreads();
             }
-            const int blk = (int)blockIdx.x + i * (int)gridDim.x;
+            const int blk = xlo + i * xstep;
             int b;
             int64_t opix;
             block_pix(blk, b, opix);
@@ -334,11 +346,11 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     for (int q = 0; q < 9; ++q) a[q] = a_at(q, 0);
     auto fill_sctab = [&](int bi) __attribute__((always_inline)) {  // in_scale[b, 0..K) of block number bi (K <= 256)
         if (bi >= count) return;
-        const int b = ((int)blockIdx.x + bi * (int)gridDim.x) / per_img;
+        const int b = (xlo + bi * xstep) / per_img;
         if (tid < K) sctab[(bi & 1) * 256 + tid] = in_scale ? in_scale[(int64_t)b * K + tid] : 1.f;
     };
     auto fill_etab = [&](int bi) __attribute__((always_inline)) {  // noise patch and per-channel epilogue operands of block number bi
-        const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+        const int blk = xlo + bi * xstep;
         const int b = blk / per_img, rem = blk - b * per_img;
         const int by = rem / bx_n, bx = rem - by * bx_n;
         if (tid < 128) {
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             if (!(skip & 4)) mfma_tick(c & 1, (c + 1) & (KC - 1));
             __syncthreads();
         }
-        const int blk = (int)blockIdx.x + i * (int)gridDim.x;
+        const int blk = xlo + i * xstep;
         int b;
         int64_t opix;
         block_pix(blk, b, opix);
@@ -432,6 +444,8 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
     if (gx > blocks) gx = (int)blocks;
     if ((wgs & 0xffff) > 0 && (wgs & 0xffff) < gx) gx = wgs & 0xffff;  // (tests: several blocks per workgroup on small inputs; bits 16+: a tuning build's skip mask)
     const dim3 g2((unsigned)gx, (unsigned)nby);
+    // XCD-contiguous block ownership (the kernel's `xmap`): needs whole eighths; W2E_TUNE_XCD bit 0 = 0 switches it off (A/B)
+    const int xmap = ((options().tune_xcd < 0 || (options().tune_xcd & 1)) && (gx & 7) == 0 && (blocks & 7) == 0 && (blocks >> 3) >= (gx >> 3)) ? 1 : 0;
     const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256 + 608) * 4;
     static unsigned done3[4];
     static unsigned done3w[4];
@@ -441,11 +455,11 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
         if (wide) {                                                                                                                        \
             W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, 16>, &done3w[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
             wino4_fused3_kernel<ACTv, DOTv, 16><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
-                                                                     noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);           \
+                                                                     noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16, xmap);     \
         } else {                                                                                                                           \
             W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, 8>, &done3[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
             wino4_fused3_kernel<ACTv, DOTv, 8><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
-                                                                    noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16);            \
+                                                                    noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16, xmap);      \
         }                                                                                                                                  \
     } while (0)
     if (act == 1) W2E_WF3(1, false, 0);
