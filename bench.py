@@ -417,7 +417,7 @@ def bench_config5(args, rank, world, device):
         "metric": "1024^2 edited images/sec, invert-and-edit inference pipeline (BASELINE configs[4])", "value": r["value"],
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": r["workload"], "global_batch": args.batch * world, "parallelism": f"replicas x{world}",
+        "config": {"workload": r["workload"], "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"replicas x{world}",
                    "stabilise_steps": r["stabilise_steps"], "stabilised": r["stabilised"], "mask_mean": r["mask_mean"],
                    "hip_graph": r["hip_graph"], "hip_graph_note": r["hip_graph_note"]}}), flush=True)
 

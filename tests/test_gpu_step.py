@@ -352,7 +352,8 @@ def test_bench_workload2_step_matches_oracle(batch, capfd):
     # deterministic option) -- the same step from the same starting parameters, captured and replayed, against the same oracle
     # results; twice, so that a replay which depends on state left by the capture (or by the previous replay) shows
     _restore_mapper(coach, osd)
-    graphed = coach.capture_step(w)
+    del x, x_hat, w_hat, loss  # (a graph held from the eager pieces above would keep the parameters' AccumulateGrad nodes, bound to
+    graphed = coach.capture_step(w)  # the default stream, alive: capture_graph refuses that -- test_capture_refuses_a_stale_graph)
     for replay in (1, 2):
         _restore_mapper(coach, osd)
         dg = graphed(w)
@@ -417,7 +418,9 @@ def test_bench_workload3_step_matches_oracle(batch):
         _restore_mapper(coach, osd)
         dg = graphed(w, mask_fn)
         torch.cuda.synchronize()
-        assert torch.equal(mask_fn.last.detach().cpu(), mask), f"replay {replay}: the captured mask branch gave another mask"
+        # (the unedited pass's activations carry the run-to-run rounding of the direct kernels' split-K atomics: the recomputed mask
+        # agrees to rounding unless a cluster mean sat within that rounding of the 0.8 threshold -- which this comparison would show)
+        assert_close(mask_fn.last.detach().cpu(), mask, 1e-5, f"replay {replay}: the mask recomputed inside the graph")
         for key, ref in (("loss_id", l_id), ("loss_clip", l_clip), ("loss_l2_latent", l_l2), ("loss", loss_o)):
             assert abs(float(dg[key]) - ref.item()) <= 2e-4 * max(abs(ref.item()), 1e-3), (replay, key, float(dg[key]), ref.item())
         flat_g = torch.cat([params[n].grad.reshape(-1).cpu() for n in names])
@@ -665,6 +668,22 @@ def test_graphed_region_step_with_callable_mask_equals_eager_step():
                 assert torch.equal(pe, pg), f"{n} after step {i}"
     finally:
         where2edit_amd.set_deterministic(False)
+
+
+def test_capture_refuses_a_stale_graph_instead_of_crashing():
+    """A loss kept from an eager step keeps the mapper parameters' AccumulateGrad nodes alive, bound to the stream of that step;
+    under capture they pull that stream into the graph and hipStreamEndCapture segfaults (hip::Stream::EndCapture).  capture_graph
+    detects it during its warm-up and raises; with the old graph dropped the capture goes through."""
+    coach, _, _ = _coach(_opts())
+    w = seeded.wplus_latents(2, OG.n_latent(SIZE), salt=61).to(DEV)
+    x, x_hat, w_hat = coach.forward_pair(w)
+    loss, _ = coach.calc_loss(w, x, w_hat, x_hat)
+    loss.backward()
+    with pytest.raises(RuntimeError, match="earlier eager step"):
+        coach.capture_step(w)
+    del x, x_hat, w_hat, loss
+    step = coach.capture_step(w)
+    assert torch.isfinite(step(w)["loss"])
 
 
 def test_capture_refuses_a_step_with_memset_operations():

@@ -272,7 +272,7 @@ class Coach:
                 loss.backward()
                 return loss_dict
 
-            graph, static_out = capture_graph(body, "capture_step: the step", self.device, warmup)
+            graph, static_out = capture_graph(body, "capture_step: the step", self.device, warmup, leaves=params)
         finally:
             self._side = eager_side
         static_grads = [p.grad for p in params]
@@ -336,7 +336,7 @@ class Coach:
         torch.save({"state_dict": self.net.state_dict(), "opts": {k: v for k, v in vars(self.opts).items()}}, path)
 
 
-def capture_graph(body, what, device, warmup=3):
+def capture_graph(body, what, device, warmup=3, leaves=()):
     """The one way this package turns a fixed-shape, stream-ordered `body()` into a hipGraph (Coach.capture_step and
     demo_pipeline.capture_invert_and_edit both come here): `warmup` eager runs on a side stream (they build every lazily cached
     pack and opt the large-LDS kernels in on this device), the memset check below, then the capture.  Returns (graph, body's
@@ -346,9 +346,27 @@ def capture_graph(body, what, device, warmup=3):
     `bench.py --workload 5 --gpus N` keeps a group alive around the pipeline's capture in the same way)."""
     side = torch.cuda.Stream(device=device)
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(warmup):
-            body()
+    # `leaves` (the trainable parameters a backward inside `body` accumulates into): autograd runs a leaf's AccumulateGrad node on
+    # the stream that was current when that node was CREATED, and the node lives as long as any graph that uses the parameter.  A
+    # graph kept from an earlier eager step (a held loss / output tensor) therefore drags the stream of that step -- normally the
+    # legacy default stream -- into the capture as a forked stream, and hipStreamEndCapture then dies in hip::Stream::EndCapture
+    # (seen with a test that held x_hat and the loss across capture_step).  Found out here, during the warm-up: a tensor hook on a
+    # leaf runs under that node's stream guard.
+    seen, hooks = set(), []
+    for p in leaves:
+        if p.requires_grad:
+            hooks.append(p.register_hook(lambda g, _s=seen: _s.add(torch.cuda.current_stream().cuda_stream) or None))
+    try:
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+    finally:
+        for h in hooks:
+            h.remove()
+    if seen - {side.cuda_stream}:
+        raise RuntimeError(f"{what}: an autograd graph from an earlier eager step still references the parameters (their gradient "
+                           "accumulation ran on another stream than the warm-up's) -- capturing now would pull that stream into the "
+                           "graph and crash in hipStreamEndCapture.  Drop the old loss / output tensors (del them) before capturing.")
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     memset_guard(body, what)
