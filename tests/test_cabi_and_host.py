@@ -310,9 +310,9 @@ def test_fused_winograd_kernel_keeps_its_hand_counted_waits():
                             "--cuda-device-only", "-o", out, src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
         text = open(out).read()
-    kernels = re.findall(r"^(_ZN3w2e19wino4_fused3_kernelILi(\d)ELb(\d)ELi(\d+)EE\w+):[^\n]*\n(.*?)^\s*\.size\s+\1,", text, flags=re.S | re.M)
-    assert len(kernels) == 8, [k[0] for k in kernels]  # 4 epilogues x 2 block shapes
-    for name, act, dot, txn, body in kernels:
+    kernels = re.findall(r"^(_ZN3w2e19wino4_fused3_kernelILi(\d)ELb(\d)ELi(\d+)ELi(\d)EE\w+):[^\n]*\n(.*?)^\s*\.size\s+\1,", text, flags=re.S | re.M)
+    assert len(kernels) == 16, [k[0] for k in kernels]  # 4 epilogues x 2 block shapes x 4 / 8 matrix waves
+    for name, act, dot, txn, mw, body in kernels:
         lines = [ln.strip() for ln in body.splitlines()]
         first = next(i for i, ln in enumerate(lines) if re.match(r"buffer_load_dwordx4 .* lds$", ln))
         region = lines[first:]

@@ -37,6 +37,7 @@ static bool apply(Options& o, const char* name, const char* value) {
     else if (!strcmp(name, "tune_gemm_s")) o.tune_gemm_s = iv;
     else if (!strcmp(name, "tune_fuse")) o.tune_fuse = (value && *value) ? iv : -1;
     else if (!strcmp(name, "tune_xcd")) o.tune_xcd = (value && *value) ? iv : -1;
+    else if (!strcmp(name, "tune_mw")) o.tune_mw = (value && *value) ? iv : -1;
 #ifdef W2E_TUNING
     else if (!strcmp(name, "tune_skip")) o.tune_skip = iv;
     else if (!strcmp(name, "tune_clock")) o.tune_clock = iv;
@@ -47,12 +48,13 @@ static bool apply(Options& o, const char* name, const char* value) {
 
 static Options from_env() {
     Options o{};
-    o.tune_cfg = -1, o.tune_cfg_splits = 1, o.tune_cfg_mode = -1, o.tune_upall = -1, o.tune_dma = -1, o.tune_fuse = -1, o.tune_xcd = -1;
+    o.tune_cfg = -1, o.tune_cfg_splits = 1, o.tune_cfg_mode = -1, o.tune_upall = -1, o.tune_dma = -1, o.tune_fuse = -1, o.tune_xcd = -1, o.tune_mw = -1;
     static const char* const kEnv[][2] = {
         {"W2E_CONV_PRECISION", "conv_precision"}, {"W2E_DETERMINISTIC", "deterministic"}, {"W2E_TUNE_CFG", "tune_cfg"},
         {"W2E_TUNE_UPALL", "tune_upall"},         {"W2E_TUNE_DMA", "tune_dma"},           {"W2E_TUNE_PRINT", "tune_print"},
         {"W2E_TUNE_BLUR", "tune_blur"},           {"W2E_TUNE_GEMM_S", "tune_gemm_s"},     {"W2E_TUNE_FUSE", "tune_fuse"},
-        {"W2E_TUNE_SKIP", "tune_skip"},           {"W2E_TUNE_CLOCK", "tune_clock"},       {"W2E_TUNE_XCD", "tune_xcd"}};
+        {"W2E_TUNE_SKIP", "tune_skip"},           {"W2E_TUNE_CLOCK", "tune_clock"},       {"W2E_TUNE_XCD", "tune_xcd"},
+        {"W2E_TUNE_MW", "tune_mw"}};
     for (const auto& e : kEnv)
         if (const char* v = getenv(e[0])) apply(o, e[1], v);
     return o;

@@ -76,8 +76,17 @@ typedef float wf_f32x2 __attribute__((ext_vector_type(2)));
 // in packed fp32 (v_pk_*_f32: see `transform_h`).  Per block: a pre-tick (chunk 0 -> V[0]), KC matrix ticks (MFMAs of chunk c | transform of chunk c+1,
 // DMA of chunk g+3), then two output rounds of 16 channels through the V space, in which all 512 threads own a (channel, tile) pair.
 // TXN: tiles of a block along x (8: blocks of 32 x 16 pixels; 16: 64 x 8 -- longer row segments per DMA, fewer cache lines per byte).
-template <int ACT, bool DOT, int TXN>
-__global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+// MW: matrix waves of a workgroup.  4 (512 threads): 32 output channels per workgroup, everything above.  8 (768 threads, three waves per
+// SIMD, <= 168 VGPRs): 64 output channels -- wave (g, hh) owns positions 9g .. 9g+8 of channel half hh, so ONE input transform feeds twice
+// the MFMAs.  Why that is the lever (profiles/r05_issue_share_probe.txt): while an fp32 MFMA executes, NO VALU instruction of any other
+// wave on that SIMD issues (a partner gets one instruction per MFMA, whatever its kind or priority; with s_nop gaps behind the MFMAs it
+// gets exactly the gaps) -- the fp32 matrix rate equals the packed-fp32 vector rate because it IS the vector ALUs.  A tick therefore
+// costs MFMA cycles PLUS transform cycles (2304 + ~900 of the 4200 measured), never their maximum, and the only way to make the
+// transform cheaper per MFMA is to share it between more output channels.  With 8 matrix waves the accumulators take 144 of a wave's
+// 168 registers: the A operands come through a ring of three positions instead of a tick ahead, and the output items (which need ~60
+// registers beside live accumulators) are all run by the transform waves, two per thread and round, in four rounds of 16 channels.
+template <int ACT, bool DOT, int TXN, int MW>
+__global__ __launch_bounds__(64 * (MW + 4), 1) void wino4_fused3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                                               const float* __restrict__ uf, const float* __restrict__ out_scale,
                                                               float* __restrict__ y, int B, int K, int N, int H, int W, int kc_log2,
                                                               int n_blocks, const float* __restrict__ noise,
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     // starts ABOVE 64 KB: the M0 base of `buffer_load ... lds` must carry byte offsets up to 147 455, which gfx950 (160 KB of LDS per
     // CU) does and earlier parts with a 16-bit field do not -- an ISA change here has to fail the build, not the numbers.
     static_assert(2 * VS * 4 == 73728 && (2 * VS + 3 * PS) * 4 == 147456, "fused Winograd kernel: LDS map of the V stages and the DMA ring");
-    static_assert((2 * VS + 3 * PS + 512 + 608) * 4 <= 160 * 1024, "fused Winograd kernel: more LDS than a gfx950 CU has");
+    static_assert((2 * VS + 3 * PS + 512 + 704) * 4 <= 160 * 1024, "fused Winograd kernel: more LDS than a gfx950 CU has");
+    static_assert(MW == 4 || MW == 8, "4 matrix waves (32 output channels per workgroup) or 8 (64)");
     static_assert((2 * VS + 3 * PS) * 4 < (1 << 18), "fused Winograd kernel: DMA ring offsets beyond M0's 18-bit LDS address");
     static_assert(6 * 4 == 24 && 24 * 64 >= PQ, "fused Winograd kernel: 4 transform waves x 6 DMA instructions must cover a patch chunk");
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // V[2][VS], ring[3][PS], in_scale table [2][256]
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     float* const sctab = ring + 3 * PS;  // in_scale[b, .] of the current / the next block, written by the matrix waves: the transform
                                          // waves issue no compiler-managed global load at all (its wait would be vmcnt(0) and drain the
                                          // DMA ring) -- the epilogue operands come the same way:
-    float* const etab = sctab + 512;     // the block's noise patch [16][32], then out_scale / bias / slope of the 32 channels
+    float* const etab = sctab + 512;     // the block's noise patch [16][32], then out_scale / bias / slope of the workgroup's 32 / 64 channels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx_n = W / BWP, by_n = H / BHP, per_img = bx_n * by_n;
@@ -126,12 +136,16 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
     const int xend = xmap ? (n_blocks >> 3) * (((int)blockIdx.x & 7) + 1) : n_blocks;
     const int count = (xend - xlo + xstep - 1) / xstep;
     const int total = count << kc_log2;
-    const int n0 = blockIdx.y * 32;
-    const int oj = tid & 31, on16 = tid >> 5;
+    constexpr int NCH = 8 * MW;  // output channels of a workgroup
+    const int n0 = blockIdx.y * NCH;
+    // item threads of an output round (16 channels x 32 tiles = 512 items): MW 4: all 512 threads; MW 8: the transform waves (items 0 .. 255)
+    // and the matrix waves of channel half 0 (256 .. 511), whose accumulators are dead or half dead by then -- half 1's are live until round 3
+    const int item_t = MW == 4 ? tid : (tid >= 64 * MW ? tid - 64 * MW : 256 + (tid & 255));
+    const int oj = item_t & 31, on16 = item_t >> 5;
     const float nw = (ACT == 1 && noise) ? noise_w[0] : 0.f;
     auto out_items = [&](int blk, int b, int64_t opix, int nloc) __attribute__((always_inline)) {  // nloc: channel within the block of 32
         const int n = n0 + nloc;
-        const float os = etab[512 + nloc], bs = etab[544 + nloc], sl = etab[576 + nloc];
+        const float os = etab[512 + nloc], bs = etab[512 + NCH + nloc], sl = etab[512 + 2 * NCH + nloc];
         const float* mp = mbuf + (nloc & 15) * 32 + oj;
         float s[4][6];
 #pragma unroll
@@ -180,9 +194,9 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         const int by = rem / bx_n, bx = rem - by * bx_n;
         opix = (int64_t)(by * BHP + 4 * (oj / TXN)) * W + bx * BWP + 4 * (oj % TXN);
     };
-    if (wave >= 4) {
+    if (wave >= MW) {
         // ---------------------------------------------------------------------------------------------- transform waves
-        const int tw = wave - 4;
+        const int tw = wave - MW;
         const int tj = tid & 31;  // tile of a block
         const uint64_t a64 = (uint64_t)(uintptr_t)x;
         i32x4 qx;
@@ -305,45 +319,60 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             block_pix(blk, b, opix);
             // (with the fused dot an item loads 16 floats of dot_with from global memory: a compiler-managed wait that drains this wave's
             // DMA ring once per block; leaving all items to the matrix waves instead measured slower: 1.04 vs 0.98 ms, 32 @ 1024^2 batch 8)
-            __syncthreads();  // A0
-            if (!(skip & 8)) out_items(blk, b, opix, on16);
-            __syncthreads();  // B0
-            __syncthreads();  // A1
-            if (!(skip & 8)) out_items(blk, b, opix, 16 + on16);
-            __syncthreads();  // B1
+            if constexpr (MW == 4) {
+                __syncthreads();  // A0
+                if (!(skip & 8)) out_items(blk, b, opix, on16);
+                __syncthreads();  // B0
+                __syncthreads();  // A1
+                if (!(skip & 8)) out_items(blk, b, opix, 16 + on16);
+                __syncthreads();  // B1
+            } else {
+                for (int r = 0; r < 4; ++r) {  // 16 channels per round; this thread's item: channel 16 r + on16 (on16 = 0 .. 7 here)
+                    __syncthreads();  // A
+                    if (!(skip & 8)) out_items(blk, b, opix, 16 * r + on16);
+                    __syncthreads();  // B
+                }
+            }
         }
         return;
     }
     // -------------------------------------------------------------------------------------------------- matrix waves
     const int half = lane >> 5, j = lane & 31;
-    const int g = wave;
+    const int g = wave & 3;  // position group
+    // The role of a matrix wave, instantiated per channel half HH (MW 8; wave-uniform branch below): the two halves differ in WHEN their
+    // accumulators die -- half 0 hands its 16-channel rounds over first and then runs output items beside the transform waves, half 1
+    // holds all 144 accumulator registers until round 2 -- and the compiler's liveness is per code path only if the paths are separate.
+    auto matrix_role = [&](auto hh_c) __attribute__((always_inline)) {
+    constexpr int hh = decltype(hh_c)::value;
     wf_f32x16 acc[9];
     // A operands, loaded one tick ahead and in place: a[q] is reloaded right behind the four MFMAs that consumed it.  Buffer loads: the
     // lane's part of the address is ONE VGPR, the (position, chunk) part a scalar offset -- no VALU address arithmetic in the wave that
     // issues the MFMAs (a wave's own instructions are never hidden by its MFMAs: tools/issue_probe.hip)
-    float4 a[9];
+    constexpr int AR = MW == 4 ? 9 : 3;  // A operands held: a tick ahead (MW 4), or a ring of three positions (MW 8: 144 accumulator registers)
+    float4 a[AR];
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uf), (short)0, (int)(unsigned)((int64_t)36 * K * N * 4), 0x00020000);
-    const int voff_a = (half * N + n0 + j) * 16;
+    const int voff_a = (half * N + n0 + 32 * hh + j) * 16;
     const unsigned stride_a = (unsigned)(2 * N) * 16u;  // bytes per (position, 8-channel chunk)
     auto a_at = [&](int q, int kc) __attribute__((always_inline)) {
         typedef float a_f32x4 __attribute__((ext_vector_type(4)));
         const a_f32x4 v = __builtin_bit_cast(a_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, voff_a, (int)((unsigned)(((9 * g + q) << kc_log2) + kc) * stride_a), 0));
         return make_float4(v.x, v.y, v.z, v.w);
     };
-    auto mfma_tick = [&](int stage, int next_kc) __attribute__((always_inline)) {
+    auto mfma_tick = [&](int stage, int cur_kc, int next_kc) __attribute__((always_inline)) {
         const float4* vs4 = reinterpret_cast<const float4*>(wsm + stage * VS);
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             const float4 b4 = vs4[((9 * g + q) * 2 + half) * 32 + j];
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b4.x, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b4.y, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b4.z, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b4.w, acc[q], 0, 0, 0);
-            a[q] = a_at(q, next_kc);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % AR].x, b4.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % AR].y, b4.y, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % AR].z, b4.z, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % AR].w, b4.w, acc[q], 0, 0, 0);
+            if constexpr (MW == 4) a[q] = a_at(q, next_kc);
+            else a[q % AR] = (q + AR < 9) ? a_at(q + AR, cur_kc) : a_at(q + AR - 9, next_kc);  // three positions (~1500 cycles) ahead
         }
     };
 #pragma unroll
-    for (int q = 0; q < 9; ++q) a[q] = a_at(q, 0);
+    for (int q = 0; q < AR; ++q) a[q] = a_at(q, 0);
     auto fill_sctab = [&](int bi) __attribute__((always_inline)) {  // in_scale[b, 0..K) of block number bi (K <= 256)
         if (bi >= count) return;
         const int b = (xlo + bi * xstep) / per_img;
@@ -357,12 +386,12 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
             const int row = tid / TXN, qd = tid % TXN;
             *reinterpret_cast<float4*>(etab + row * BWP + 4 * qd) =
                 (ACT == 1 && noise) ? *reinterpret_cast<const float4*>(noise + (int64_t)(by * BHP + row) * W + bx * BWP + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (tid < 160) {
+        } else if (tid < 128 + NCH) {
             etab[512 + tid - 128] = out_scale ? out_scale[(int64_t)b * N + n0 + tid - 128] : 1.f;
-        } else if (tid < 192) {
-            etab[544 + tid - 160] = (ACT && bias) ? bias[n0 + tid - 160] : 0.f;
-        } else if (tid < 224) {
-            etab[576 + tid - 192] = (ACT == 2 && slope) ? slope[n0 + tid - 192] : 1.f;
+        } else if (tid < 128 + 2 * NCH) {
+            etab[512 + NCH + tid - 128 - NCH] = (ACT && bias) ? bias[n0 + tid - 128 - NCH] : 0.f;
+        } else if (tid < 128 + 3 * NCH) {
+            etab[512 + 2 * NCH + tid - 128 - 2 * NCH] = (ACT == 2 && slope) ? slope[n0 + tid - 128 - 2 * NCH] : 1.f;
         }
     };
     fill_sctab(0);
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         fill_etab(i);     // (the previous block's output rounds are behind the last barrier; this block's come KC ticks later)
         __syncthreads();  // pre-tick
         for (int c = 0; c < KC; ++c) {
-            if (!(skip & 4)) mfma_tick(c & 1, (c + 1) & (KC - 1));
+            if (!(skip & 4)) mfma_tick(c & 1, c, (c + 1) & (KC - 1));
             __syncthreads();
         }
         const int blk = xlo + i * xstep;
@@ -384,8 +413,9 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
         block_pix(blk, b, opix);
         fill_sctab(i + 1);  // (the last transform of block i was one tick ago; the table of block i+1 is read from its pre-tick on)
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {  // (unrolled: the accumulator registers are indexed by q2)
-            if (!(skip & 8)) {
+        for (int r = 0; r < MW / 2; ++r) {  // (unrolled: the accumulator registers are indexed by q2)
+            const int q2 = r & 1;
+            if (!(skip & 8) && (MW == 4 || hh == (r >> 1))) {  // (MW 8: rounds 0, 1 = channel half 0, rounds 2, 3 = half 1)
 #pragma unroll
                 for (int q = 0; q < 9; ++q)
 #pragma unroll
@@ -393,10 +423,15 @@ __global__ __launch_bounds__(512, 1) void wino4_fused3_kernel(const float* __res
                         mbuf[((9 * g + q) * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * half) * 32 + j] = acc[q][8 * q2 + rr];
             }
             __syncthreads();  // A
-            if (!(skip & 8)) out_items(blk, b, opix, 16 * q2 + on16);
+            if constexpr (MW == 4 || hh == 0) {
+                if (!(skip & 8)) out_items(blk, b, opix, 16 * r + on16);
+            }
             __syncthreads();  // B
         }
     }
+    };  // matrix_role
+    if (MW == 8 && (wave >> 2)) matrix_role(std::integral_constant<int, 1>{});  // (wave-uniform)
+    else matrix_role(std::integral_constant<int, 0>{});
 }
 
 }  // namespace w2e
@@ -438,7 +473,10 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
     int kc_log2 = 0;
     while ((8 << kc_log2) < k_ch) ++kc_log2;
     const int cus = cu_count();
-    const int nby = n_ch / 32;
+    // 8 matrix waves / 64 output channels per workgroup wherever the layer has them (one input transform per 64 instead of per 32
+    // channels; the kernel's comment says why that is what pays); W2E_TUNE_MW=4 keeps the 32-channel form (A/B)
+    const bool mw8 = (n_ch & 63) == 0 && options().tune_mw != 4;
+    const int nby = n_ch / (mw8 ? 64 : 32);
     int gx = cus / nby;
     if (gx < 1) gx = 1;
     if (gx > blocks) gx = (int)blocks;
@@ -446,26 +484,28 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
     const dim3 g2((unsigned)gx, (unsigned)nby);
     // XCD-contiguous block ownership (the kernel's `xmap`): needs whole eighths; W2E_TUNE_XCD bit 0 = 0 switches it off (A/B)
     const int xmap = ((options().tune_xcd < 0 || (options().tune_xcd & 1)) && (gx & 7) == 0 && (blocks & 7) == 0 && (blocks >> 3) >= (gx >> 3)) ? 1 : 0;
-    const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256 + 608) * 4;
-    static unsigned done3[4];
-    static unsigned done3w[4];
+    const size_t lds3 = (size_t)(2 * 36 * 2 * 32 * 4 + 3 * 24 * 64 * 4 + 2 * 256 + 704) * 4;
+    static unsigned done3[4][4];  // [epilogue][block shape x matrix waves]
     const bool wide = (w & 63) == 0 && !((wgs >> 16) & 16);  // blocks of 64 x 8 pixels (bit 4 of a tuning build's mask: keep 32 x 16)
-#define W2E_WF3(ACTv, DOTv, slot)                                                                                                          \
+#define W2E_WF3_(ACTv, DOTv, TXNv, MWv, slot, sub)                                                                                          \
     do {                                                                                                                                   \
-        if (wide) {                                                                                                                        \
-            W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, 16>, &done3w[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
-            wino4_fused3_kernel<ACTv, DOTv, 16><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
-                                                                     noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16, xmap);     \
-        } else {                                                                                                                           \
-            W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, 8>, &done3[slot]), "wino_fused: cannot enable %zu B of LDS", lds3); \
-            wino4_fused3_kernel<ACTv, DOTv, 8><<<g2, 512, lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2, (int)blocks, \
-                                                                    noise, noise_w, bias, slope, dot_with, dot_out, wgs >> 16, xmap);      \
-        }                                                                                                                                  \
+        W2E_REQUIRE(big_lds_once((const void*)wino4_fused3_kernel<ACTv, DOTv, TXNv, MWv>, &done3[slot][sub]), "wino_fused: cannot enable %zu B of LDS", lds3); \
+        wino4_fused3_kernel<ACTv, DOTv, TXNv, MWv><<<g2, 64 * (MWv + 4), lds3, s>>>(x, in_scale, uf, out_scale, y, batch, k_ch, n_ch, h, w, kc_log2,      \
+                                                                                   (int)blocks, noise, noise_w, bias, slope, dot_with, dot_out,      \
+                                                                                   wgs >> 16, xmap);                                                 \
+    } while (0)
+#define W2E_WF3(ACTv, DOTv, slot)                                     \
+    do {                                                              \
+        if (wide && mw8) W2E_WF3_(ACTv, DOTv, 16, 8, slot, 0);        \
+        else if (wide) W2E_WF3_(ACTv, DOTv, 16, 4, slot, 1);          \
+        else if (mw8) W2E_WF3_(ACTv, DOTv, 8, 8, slot, 2);            \
+        else W2E_WF3_(ACTv, DOTv, 8, 4, slot, 3);                     \
     } while (0)
     if (act == 1) W2E_WF3(1, false, 0);
     else if (act == 2) W2E_WF3(2, false, 1);
     else if (dot_with) W2E_WF3(0, true, 2);
     else W2E_WF3(0, false, 3);
+#undef W2E_WF3_
 #undef W2E_WF3
     W2E_LAUNCH_CHECK("wino_fused");
     return 0;
