@@ -102,7 +102,7 @@ def test_attention_map_at_ffhq1024_shapes_vs_oracle():
         assert abs(float(a_) - float(b_)) <= 1e-4 * max(abs(float(b_)), 1e-3), name
 
 
-def _trainer(size=256, consistency="recompute", identity=False):
+def _trainer(size=256, consistency="recompute", identity=False, amp=False):
     import types
     from make_golden import CLIP_TINY as c
     from where2edit_amd.attention_model import Generator
@@ -123,7 +123,7 @@ def _trainer(size=256, consistency="recompute", identity=False):
     net.load_state_dict(msd, strict=True)
     opts = types.SimpleNamespace(stylegan_size=size)
     tr = RegionAttentionTrainer(g, CLIPLoss(opts, model=clip), net, attention_layer=M.ATT_LAYER, lr=0.01, steps=100,
-                                consistency=consistency, device=DEV)
+                                consistency=consistency, device=DEV, amp=amp)
     return tr, gsd, csd, msd, c["embed_dim"]
 
 
@@ -178,6 +178,36 @@ def test_region_attention_trainer_step_matches_oracle():
                       "trainable mapper parameters")
     moved = [n for n, p in params.items() if not torch.equal(p.detach(), before[n])]
     assert moved and all(n.startswith("mapper_") for n in moved)
+
+
+def test_region_attention_trainer_amp_keeps_the_gradscaler_protocol():
+    """`amp=True` (the reference's --amp: run_attention.py:1068-1069, 1418-1421): the loss is scaled before backward, scaler.step unscales
+    and steps -- the scale is a power of two, so with finite gradients three steps leave the parameters bit-identical to amp=False -- and
+    a step whose gradient is not finite is SKIPPED (parameters untouched) while the scale backs off."""
+    import where2edit_amd
+    lat = lambda salt: seeded.wplus_latents(1, 14, salt=salt).to(DEV)  # noqa: E731  (Generator(256): 14 latents)
+    runs = []
+    where2edit_amd.set_deterministic(True)  # (no fp32 atomics: two runs of the same step are bit-identical, so amp on / off can be compared exactly)
+    try:
+        for amp in (False, True):
+            tr, _, _, _, edim = _trainer(amp=amp)
+            text = seeded.tensor("amp.att", (1, edim), 0.3).to(DEV)
+            for i in range(3):
+                tr.train_step(lat(200 + i), lat(300 + i), text)
+            runs.append(tr)
+    finally:
+        where2edit_amd.set_deterministic(False)
+    a, b = runs
+    assert b.scaler.is_enabled() and not a.scaler.is_enabled() and b.scaler.get_scale() == 65536.0
+    for (n, pa), (_, pb) in zip(a.mapper.named_parameters(), b.mapper.named_parameters()):
+        assert torch.equal(pa, pb), n
+    before = {n: p.detach().clone() for n, p in b.mapper.named_parameters()}
+    poisoned = next(p for p in b.params)
+    h = poisoned.register_hook(lambda g: g * float("inf"))  # an overflowing backward
+    b.train_step(lat(210), lat(310), text)
+    h.remove()
+    assert all(torch.equal(before[n], p.detach()) for n, p in b.mapper.named_parameters()), "a non-finite step was applied"
+    assert b.scaler.get_scale() == 32768.0
 
 
 def test_gpu_lloyd_matches_cpu_lloyd():

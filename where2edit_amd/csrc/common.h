@@ -18,7 +18,8 @@ struct Options {
     int tune_cfg, tune_cfg_splits, tune_cfg_mode;  // force a conv tile (tests / tools/layer_bench.py); -1 = off
     int tune_upall, tune_dma, tune_fuse;  // -1 = the library's own choice, 0 never, 1 always
     int tune_mw;   // matrix waves of the fused Winograd kernel: -1 = 8 wherever N % 64 == 0; 4 = always the 32-channel form
-    int tune_xcd;  // XCD-contiguous tile ownership: -1 = the library's choice per kernel; else a mask: 1 fused Winograd, 2 direct conv, 4 FIR
+    int tune_xcd;  // XCD-contiguous block ownership in the fused Winograd kernel: -1 / 1 = on (default), 0 = the old round-robin order (A/B).
+                   // (Measured and not kept for the direct kernel: same FETCH_SIZE, same time -- profiles/r05_xcd_map_ab.txt)
     int tune_print, tune_blur, tune_gemm_s;
     int tune_skip, tune_clock;  // only honoured by a -DW2E_TUNING build (they skip work / synchronise)
 };

@@ -61,9 +61,6 @@ struct ConvParams {
     int in_off;          // DOWN: the input origin is shifted by in_off (-1 = a stride-2 convolution with padding 1 of an in_h x in_w image)
     int splits, k_per;  // split-K: workgroup ks reduces channels [ks*k_per, (ks+1)*k_per) and adds atomically
     unsigned long long* stamps;  // tuning aid (W2E_TUNE_CLOCK): per workgroup {s_memtime, s_memrealtime} at start and end
-    int xmap_g8;  // > 0: an eighth of the tile workgroups -- workgroup ids are dealt round-robin to the 8 XCDs, so the ids with equal
-                  // (id & 7) are given a CONTIGUOUS eighth of the tile order (x fastest, then y): a tile's neighbours, whose patch
-                  // halos share its 128-byte lines, run on the same XCD and find them in its L2 (W2E_TUNE_XCD bit 1)
 };
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DOT = 2, EPI_PRELU = 3 };
@@ -405,7 +402,6 @@ __global__ __launch_bounds__(64 * WO * WP, 2) void modconv_kernel(ConvParams p) 
         }
         bid -= p.border_wgs;
     }
-    if (p.xmap_g8) bid = (bid & 7) * p.xmap_g8 + (bid >> 3);
     // UP: phase-major grid, phase 0 (4 taps) first so the light phases fill the tail; (py,px) = (phase>>1, phase&1)
     const int per_phase = (gridDim.x - p.border_wgs) >> 2;
     const int phase = (MODE == W2E_CONV_UP) ? bid / per_phase : 0;
@@ -1367,7 +1363,6 @@ static int conv_impl(int mode, const float* x, const float* wp, const float* in_
     }
     const int64_t grid = (int64_t)p.tiles_x * p.tiles_y * p.tiles_n * batch * ((up && !use_all) ? 4 : 1) * p.splits + p.border_wgs;
     W2E_REQUIRE(grid < ((int64_t)1 << 31), "modconv3x3: grid of %lld workgroups is too large", (long long)grid);  // (cast to int at every launch below)
-    p.xmap_g8 = (opt.tune_xcd >= 0 && (opt.tune_xcd & 2) && ((grid - p.border_wgs) & 7) == 0) ? (int)((grid - p.border_wgs) >> 3) : 0;
 #ifdef W2E_TUNING
     // tuning aid: W2E_TUNE_CLOCK=1 stamps every workgroup and reports the in-kernel shader clock (s_memtime ticks per
     // 100 MHz s_memrealtime tick) of every 64th launch -- the DVFS-limited clock is what an MFMA-bound kernel is priced by

@@ -372,7 +372,7 @@ class RegionAttentionTrainer:
     (not in this image); callers pass CLIP text features / token ids."""
 
     def __init__(self, g_ema, clip_loss, mapper, *, attention_layer=13, lr=0.01, steps=10000, lambda_ess=0.03, lambda_sec=0.01,
-                 lambda_id=0.1, lambda_delta=0.03, identity_loss=None, consistency="recompute", device="cuda:0"):
+                 lambda_id=0.1, lambda_delta=0.03, identity_loss=None, consistency="recompute", device="cuda:0", amp=False):
         from . import dist as w2e_dist
         self.device = device
         self.g_ema = g_ema.to(device).eval().requires_grad_(False)
@@ -390,6 +390,14 @@ class RegionAttentionTrainer:
         self.consistency = consistency
         self.params = [p for p in self.mapper.parameters() if p.requires_grad]
         self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        # `--amp` (run_attention.py:1068-1069, 1231, 1418-1421): the reference wraps the mapper + generator forward in autocast and drives
+        # the optimizer through a GradScaler.  The kernels of this package compute in fp32 only, so there is nothing to autocast (a
+        # narrower forward would also leave the north_star tolerance); what `amp=True` keeps is the GradScaler protocol -- the loss is
+        # scaled before backward, the (all-reduced) gradients are unscaled and checked, a step with a non-finite gradient is SKIPPED
+        # and the scale backs off -- so a run configured with --amp keeps its skip-on-overflow behaviour.  The scale is a power of two:
+        # with finite gradients the parameters after a step are bit-identical to amp=False.
+        self.amp = bool(amp)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
         import torch.distributed as dist
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
@@ -480,10 +488,11 @@ class RegionAttentionTrainer:
         else:
             self.optimizer.zero_grad()
         total, d, _ = self.losses(w1, w2, attention_text_features)
-        total.backward()
+        self.scaler.scale(total).backward()  # (:1418; the identity when amp is off)
         if self.bucket is not None:
-            self.bucket.all_reduce_mean()  # DDP's averaged gradient (X1), one flat message
-        self.optimizer.step()
+            self.bucket.all_reduce_mean()  # DDP's averaged gradient (X1), one flat message (of the scaled gradients: every rank holds the same scale)
+        self.scaler.step(self.optimizer)   # (:1419-1420: unscale, skip the step on inf / nan)
+        self.scaler.update()               # (:1421)
         self.global_step += 1
         return d
 
