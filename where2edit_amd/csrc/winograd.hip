@@ -475,7 +475,9 @@ int w2e_wino_fused(const float* x, const float* in_scale, const float* uf, const
     const int cus = cu_count();
     // 8 matrix waves / 64 output channels per workgroup wherever the layer has them (one input transform per 64 instead of per 32
     // channels; the kernel's comment says why that is what pays); W2E_TUNE_MW=4 keeps the 32-channel form (A/B)
-    const bool mw8 = (n_ch & 63) == 0 && options().tune_mw != 4;
+    // -- unless that leaves CUs without a workgroup (128 -> 128 @ 64^2, batch 8: 64 blocks x 2 channel blocks = 128 workgroups, 57.8 us
+    // against 41 with 256 workgroups of 32 channels; profiles/r05_irse_shapes.txt)
+    const bool mw8 = (n_ch & 63) == 0 && options().tune_mw != 4 && (options().tune_mw == 8 || blocks * (n_ch / 64) >= cus);
     const int nby = n_ch / (mw8 ? 64 : 32);
     int gx = cus / nby;
     if (gx < 1) gx = 1;

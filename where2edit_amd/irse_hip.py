@@ -46,14 +46,15 @@ def _wino_form(b, k, n, h, w):
     """The Winograd F(4x4,3x3) form (functional.py, K1w / K1g) of one stride-1 3x3 conv of the IR-SE50 / e4e encoders, or 0: the fused kernel
     for the narrow high-resolution stages, the GEMM form (own MFMA contraction, output transform in its epilogue) where the channel counts
     allow -- also for 14^2 / 7^2, whose last tile row / column hangs over the image (the ragged form) --, the direct kernel where the call
-    is too small to pay for two or three launches (profiles/r04_irse_shapes.txt)."""
+    is too small to pay for two or three launches (profiles/r05_irse_shapes.txt)."""
     if K.WINOGRAD is False:
         return 0
     if _lib.get_option("conv_precision") != 0 or _lib.get_option("tune_cfg") >= 0:
         return 0
-    # Measured per shape (profiles/r04_irse_shapes.txt; batch 8 of the e4e encoder / batch 16 of the id-loss network, us, direct / GEMM
-    # form / fused): 64 -> 64 @ 256^2 302 / 254 / 167; 64 -> 64 @ 128^2 81 / 49 / 45; 64 -> 128 @ 128^2 147 / 72 / 86; 128 -> 128 @ 64^2
-    # 80 / 53 / 41; 128 -> 256 @ 64^2 150 / 57 / 77; 256 -> 256 @ 32^2 88 / 45 / 70; 64 -> 64 @ 112^2 (batch 16) 162 / 87 / -;
+    # Measured per shape (profiles/r05_irse_shapes.txt, the fused kernel with 64 output channels per workgroup where the grid fills the
+    # chip; batch 8 of the e4e encoder / batch 16 of the id-loss network, us, direct / GEMM form / fused): 64 -> 64 @ 256^2 306 / 255 /
+    # 137; 64 -> 64 @ 128^2 81 / 49 / 37; 64 -> 128 @ 128^2 148 / 73 / 73; 128 -> 128 @ 64^2 81 / 51 / 41 (32-channel workgroups: 64
+    # blocks); 128 -> 256 @ 64^2 152 / 58 / 59; 256 -> 256 @ 32^2 88 / 44 / 103; 64 -> 64 @ 112^2 (batch 16) 163 / 89 / -;
     # 64 -> 128 @ 56^2 87 / 42; 128 -> 256 @ 28^2 80 / 55; 256 -> 256 @ 14^2 54 / 45; 256 -> 512 @ 14^2 89 / 53; 512 -> 512 @ 7^2 65 / 50;
     # below ~3 GFLOP of direct work per call the direct kernel wins (64 -> 64 @ 56^2, batch 8: 26 / 39; 256 -> 256 @ 14^2, batch 8: 33 / 42).  The fused kernel repeats its input transform per 32 output channels, the GEMM form pays one pass over V:
     # fused where the layer does not widen (N <= K <= 128), the GEMM form otherwise.
