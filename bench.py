@@ -253,7 +253,7 @@ def rehearse(args):
     2 ms sleep whose length depends on the rank (so that the ranks would leave the stabilisation loop after different numbers of
     steps if they decided alone) + the all-reduce of a LevelsMapper-sized bucket (3.15 M floats) of host memory over gloo."""
     from where2edit_amd import dist as wd
-    rank, world, _ = wd.init_from_env(backend="gloo", timeout_s=120)
+    rank, world, _ = wd.init_from_env(backend="gloo", timeout_s=120, use_gpu=False)  # (no rank may open the GPU: see its docstring)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     bucket = torch.zeros(3_150_000)

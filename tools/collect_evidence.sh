@@ -67,11 +67,11 @@ timeout -k 10 200 python3 tools/cfg_selections.py $O/cfg_selections.txt > /dev/n
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/pk_probe.hip -o /tmp/pk_probe 2> /dev/null && /tmp/pk_probe > $O/pk_probe.txt 2>&1 || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -Wno-unused-value tools/issue_share_probe.hip -o /tmp/isp 2> /dev/null && /tmp/isp > $O/issue_share_probe.txt 2>&1 || true
 echo extras done
-# round 5: the strong-scaling mode at N = 1 (global batch 64 as 8 micro-batches of 8), the 6-rank launcher run on this one GPU (gloo; a GPU box
+# round 5: the strong-scaling mode at N = 1 (global batch 64 as 8 micro-batches of 8), the 4-rank launcher run on this one GPU (gloo; a GPU box
 # allows 6 processes on its card -- the 8-rank control flow is rehearsed without GPU work by `bench.py --gpus 8 --rehearse`, tests/test_dist_cpu.py),
 # the same A/B of the fused kernel's two round-5 switches
 timeout -k 10 300 python3 bench.py --scaling strong --no-cpu-baseline > $O/bench_line_strong_n1.json 2> $O/bench_line_strong_n1.err || true
-timeout -k 10 400 python3 bench.py --gpus 6 --dist-backend gloo --batch 1 --steps 3 --warmup 2 > $O/bench_line_gloo6.json 2> $O/bench_line_gloo6.err || true
+timeout -k 10 400 python3 bench.py --gpus 4 --dist-backend gloo --batch 1 --steps 3 --warmup 2 > $O/bench_line_gloo4.json 2> $O/bench_line_gloo4.err || true
 timeout -k 10 120 python3 bench.py --gpus 8 --rehearse --steps 5 --warmup 2 > $O/bench_rehearse8.json 2> $O/bench_rehearse8.err || true
 for sw in "W2E_TUNE_MW=4 W2E_TUNE_XCD=0" "W2E_TUNE_MW=4" ""; do
 echo "== ${sw:-default (64-channel workgroups, XCD-contiguous blocks)}, batch 8" >> $O/fused_ab.txt

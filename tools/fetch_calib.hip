@@ -11,7 +11,7 @@
 //   P2  buffer_load_dwordx4 ... lds, rows of 18 quads = 288 B starting 16 B BEFORE a 256-B boundary: the fused Winograd kernel's
 //       patch rows for 64 x 8-pixel blocks (image columns bx*64-4 .. bx*64+67).  Row segments are disjoint here (every second block
 //       column), so the bytes requested are known exactly: 288 per row, in 4 lines of 128 B (2 of them touched for 16 B only)
-//   P3  the same with rows of 10 quads = 160 B (32 x 16-pixel blocks): 160 B in 3 lines
+//   P3  the same with rows of 10 quads = 160 B (32 x 16-pixel blocks): 160 B touching 3 lines, the outer two shared with the next segment
 //   P4  buffer_load_dword ... lds, 256 B contiguous per wave-instruction
 //   P5  buffer_load_dword ... lds, lane = (pixel l >> 2, plane l & 3): 4 planes x 64 B per instruction -- the direct conv kernel's
 //       channel-interleaving patch load (consecutive instructions continue each 64-B run)
@@ -130,7 +130,9 @@ int main() {
         const unsigned rows = (unsigned)(GiB / kRow), segs = rows * 15u;
         const unsigned n = (unsigned)(((uint64_t)segs * 10u) / 64u);
         const double quads = (double)n * 64.0, nseg = quads / 10.0;
-        run<3>("buffer_load_dwordx4 lds rows of 160 B at 128k-16", GiB, n, quads * 16.0, nseg * 3 * 128.0, nseg * 4 * 64.0, nseg * 6 * 32.0);
+        // (distinct 128-B lines: the segment's own line + the two neighbours it touches for 16 B each, each of which it SHARES with the next
+        // segment of the row -- segments sit in every second 128-B block -- so 2 lines per segment, not 3)
+        run<3>("buffer_load_dwordx4 lds rows of 160 B at 128k-16", GiB, n, quads * 16.0, nseg * 2 * 128.0, nseg * 4 * 64.0, nseg * 6 * 32.0);
     }
     {   // P4 / P6: 256 MiB, 256 B per instruction
         const size_t sz = GiB / 4;

@@ -12,19 +12,21 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, timeout_s=None, force_group=False):
+def init_from_env(backend=None, timeout_s=None, force_group=False, use_gpu=True):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
     Returns (rank, world_size, local_rank).  World size 1 needs no process group.  `timeout_s`: the process group's
     collective timeout (a benchmark wants a rank that lost its partners to fail in minutes, not in the default 10-30).
-    `force_group`: create the group at world size 1 too (tools/dp_rccl_selftest.py: the RCCL code path on a one-GPU box)."""
+    `force_group`: create the group at world size 1 too (tools/dp_rccl_selftest.py: the RCCL code path on a one-GPU box).
+    `use_gpu=False`: a host-only rendezvous (bench.py --rehearse): no call that initialises the GPU -- a GPU box admits only a few
+    processes on its card, and an 8-rank rehearsal must not be 8 of them."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+            backend = "nccl" if (use_gpu and torch.cuda.is_available()) else "gloo"  # "nccl" IS RCCL on ROCm
         kw = {}
-        if torch.cuda.is_available():
+        if use_gpu and torch.cuda.is_available():
             dev = local % torch.cuda.device_count()
             torch.cuda.set_device(dev)
             if backend == "nccl":  # bind the communicator to this rank's GPU at creation (RCCL otherwise guesses it from the
@@ -33,7 +35,7 @@ def init_from_env(backend=None, timeout_s=None, force_group=False):
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=timeout_s)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    elif torch.cuda.is_available():
+    elif use_gpu and torch.cuda.is_available():
         # every kernel of libw2e.so launches on the CURRENT device's stream: make the rank's GPU current whatever the
         # backend and world size (gloo self-tests may map several ranks onto one GPU)
         torch.cuda.set_device(local % torch.cuda.device_count())
