@@ -143,9 +143,11 @@ def _run_bench(argv, env=None, timeout=300):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable] + argv, cwd=root, env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=timeout)
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # (gloo's C++ side prints its own
-    #                                                                connection notes to stdout under torchrun; RCCL runs have none)
-    return r, lines, (json.loads(lines[0]) if len(lines) == 1 and lines[0].startswith("{") else None)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    # the JSON line(s) of stdout.  (Under torchrun every rank shares this stdout and gloo's C++ side prints its own connection notes
+    # there, sometimes interleaved mid-line between ranks; RCCL runs have none.  bench.py's own launcher keeps stdout to the one line.)
+    js = [ln for ln in lines if ln.startswith("{")]
+    return r, lines, (json.loads(js[0]) if len(js) == 1 else None)
 
 
 def test_bench_launcher_rehearsal_at_world_8():
@@ -156,7 +158,7 @@ def test_bench_launcher_rehearsal_at_world_8():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r, lines, out = _run_bench([os.path.join(root, "bench.py"), "--gpus", "8", "--rehearse", "--steps", "3", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
-    assert out is not None, (lines, r.stderr[-1000:])  # exactly one line on stdout, and it is JSON
+    assert out is not None and len(lines) == 1, (lines, r.stderr[-1000:])  # exactly one line on stdout, and it is JSON
     assert out["n_gpus"] == 8 and out["rehearsal"] is True and out["value"] is None and out["steps"] == 3
     assert out["steps_run_per_rank"] == out["stabilise_steps"] + 1 + 3  # every rank ran the same number of collectives
 
