@@ -473,6 +473,10 @@ def main():
     ap.add_argument("--no-n1-reference", action="store_true",
                     help="N > 1: skip the K extra steps WITHOUT the gradient all-reduce that give the line its one-GPU figure at "
                          "the same per-GPU batch (`n1_equal_batch`)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="w2e_set_option(NAME, VALUE) before the run -- for same-box A/Bs of a kernel switch inside the real step (e.g. "
+                         "tune_mw=4: the fused Winograd kernel's 32-channel workgroups; tune_xcd=0: its old block order); recorded in "
+                         "config.lib_options, so a line measured with one says so.  (The W2E_TUNE_* environment variables stay refused.)")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher rehearsal WITHOUT any GPU work (runs where there is no GPU, at any world size): the real control flow "
                          "of an N-rank run -- self-launch or torchrun environment, gloo rendezvous, the collective stop rule of the "
@@ -509,6 +513,9 @@ def main():
     device = f"cuda:{local % max(n_dev, 1)}"
     torch.cuda.set_device(device)
     _lib.set_option("conv_precision", args.conv_precision)
+    for kv in args.lib_option:
+        name, _, val = kv.partition("=")
+        _lib.set_option(name, val)
     if args.workload == 5:
         return bench_config5(args, rank, world, device)
     strong = args.scaling == "strong"
@@ -630,7 +637,8 @@ def main():
                                 f"+ clip_loss + id_loss (IR-SE50), batch {args.batch}/GPU, LevelsMapper, Ranger, id_lambda=0.1"),
                    "global_batch": global_batch, "per_gpu_batch": per_gpu, "micro_batch": args.batch, "micro_batches_per_step": n_micro,
                    "parallelism": f"dp{world}", "conv_precision": args.conv_precision, "final_loss": loss,
-                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "mask_mean": (float(mask.last.mean()) if hasattr(mask, "last") else None), "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None},
+                   "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "mask_mean": (float(mask.last.mean()) if hasattr(mask, "last") else None), "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None,
+                   "lib_options": args.lib_option or None},
     }
     if n1_ref is not None:
         out["n1_equal_batch"] = n1_ref
