@@ -268,9 +268,11 @@ def rehearse(args):
             bucket.div_(world)
         return {"loss": bucket[0]}
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+    sync_word = torch.zeros(1)
+
+    def barrier():  # (an all-reduce of a host word: torch.distributed.barrier() picks a device and OPENS the GPU even on gloo -- seen on a GPU
+        if world > 1:  # box, where 8 rehearsal ranks then ran into the 6-processes-per-card guard)
+            torch.distributed.all_reduce(sync_word)
 
     n_stab, ok = stabilise(step, world=world, device="cpu", sync=lambda: None, max_seconds=10.0)
     for _ in range(args.warmup):
