@@ -10,7 +10,13 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import socket  # noqa: E402
+
+_s = socket.socket()
+_s.bind(("127.0.0.1", 0))  # (a free port: a fixed one collides with whatever else rendezvous on the box)
+_port = _s.getsockname()[1]
+_s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 SIZE = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 from where2edit_amd import dist as wd  # noqa: E402
