@@ -461,6 +461,10 @@ def main():
                     help="f32 (default): exact fp32 MFMA everywhere.  bf16x3: the SAME-resolution and up-sampling conv tiles compute each fp32 "
                          "product as three bf16 products (hi*hi + hi*lo + lo*hi, ~2^-17 relative error per product; every "
                          "parity test passes with it) -- opt-in, reported as dtype bf16x3")
+    ap.add_argument("--clip-precision", default="f32", choices=["f32", "f16"],
+                    help="f32 (default): the CLIP tower on exact fp32 MFMA.  f16: the four Linear layers of every block take fp16 operands "
+                         "(fp32 accumulation) -- the arithmetic of the fp16 model the reference loads on a GPU (criteria/clip_loss.py:10); "
+                         "opt-in, recorded in config.clip_precision and in dtype; the default line only carries it as `clip_f16_preview`")
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE configs index + 1: 2 = clip_loss mapper step (the headline, default); 3 = the same step with "
                          "the region-attention mask blend at layer 13 and id_loss (quoted at batch 8); 5 = the inference pipeline "
@@ -524,6 +528,8 @@ def main():
     per_gpu = args.global_batch // world if strong else args.batch  # latents this GPU processes per step
     n_micro = per_gpu // args.batch                                  # ... as this many passes of --batch latents (1 unless strong)
     coach = build_coach(args.size, args.batch, device, world > 1 or strong, 'hip', args.workload)
+    if args.clip_precision != "f32":
+        coach.clip_loss.model.set_precision(args.clip_precision)
     w_all = synthetic_latents(coach.net.decoder, per_gpu, rank)
     chunks = list(w_all.split(args.batch))
     w = chunks[0]
@@ -621,7 +627,7 @@ def main():
         "metric": "1024^2 edited images/sec per mapper step" if args.size == 1024 else f"{args.size}^2 edited images/sec per mapper step",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": args.conv_precision, "data": "synthetic",
+        "dtype": args.conv_precision + ("" if args.clip_precision == "f32" else f" (CLIP block GEMM operands {args.clip_precision})"), "data": "synthetic",
         "config": {"workload": ((f"BASELINE configs[1]: " if (world == 1 and per_gpu == 4 and args.size == 1024) else
                                  f"BASELINE configs[3] (FFHQ-1024 mapper training, global batch {global_batch}, data-parallel over {world} GPUs, "
                                  f"RCCL all-reduce of the mapper gradients): " if (global_batch == 64 and args.size == 1024) else
@@ -640,7 +646,7 @@ def main():
                    "global_batch": global_batch, "per_gpu_batch": per_gpu, "micro_batch": args.batch, "micro_batches_per_step": n_micro,
                    "parallelism": f"dp{world}", "conv_precision": args.conv_precision, "final_loss": loss,
                    "stabilise_steps": stab_steps, "stabilised": stab_ok, "hip_graph": bool(args.graph), "hip_graph_note": graph_note, "mask_mean": (float(mask.last.mean()) if hasattr(mask, "last") else None), "side_stream": bool(args.side_stream and args.graph), "dist_backend": args.dist_backend if world > 1 else None,
-                   "lib_options": args.lib_option or None},
+                   "lib_options": args.lib_option or None, "clip_precision": args.clip_precision},
     }
     if n1_ref is not None:
         out["n1_equal_batch"] = n1_ref
@@ -718,6 +724,23 @@ def main():
                                  "dtype": "bf16x3", "final_loss": float(last2["loss"]),
                                  "note": "opt-in --conv-precision bf16x3: each fp32 product of the 3x3 convs as three bf16 MFMA products "
                                          "(all parity tests pass with it; DESIGN.md section 7); not the headline"}
+    if world == 1 and not strong and args.conv_precision == "f32" and args.clip_precision == "f32" and not args.no_preview and coach is not None:
+        # and once more with the opt-in fp16 operands in the CLIP tower's block GEMMs (what the reference's GPU tower computes): beside the
+        # headline, never `value`
+        coach.clip_loss.model.set_precision("f16")
+        for _ in range(5):
+            coach.train_step(w, mask)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            last3_ = coach.train_step(w, mask)
+        barrier()
+        dt3_ = time.perf_counter() - t1
+        coach.clip_loss.model.set_precision("f32")
+        out["clip_f16_preview"] = {"value": global_batch * args.steps / dt3_, "unit": "images/s", "ms_per_step": 1e3 * dt3_ / args.steps,
+                                   "final_loss": float(last3_["loss"]), "eager": True,
+                                   "note": "opt-in --clip-precision f16 (eager steps, like bf16x3_preview): the CLIP tower's four Linear layers per block "
+                                           "on fp16 operands with fp32 accumulation, criteria/clip_loss.py:10's GPU arithmetic; not the headline"}
     if world == 1 and not strong and args.workload == 2 and args.size == 1024 and args.batch == 4 and args.conv_precision == "f32" and not args.no_n1_b8:
         # the same step at 8 latents per GPU = the per-GPU workload of `--gpus N > 1` (BASELINE configs[3]), so that the driver's
         # N-GPU values have a 1-GPU figure at equal per-GPU batch beside the configs[1] headline.  Never `value`.

@@ -84,6 +84,16 @@ int w2e_gemm_pk(const float* a_packed, const float* b_packed, float* c, int m, i
                 int splits, void* stream);
 /* The K split w2e_gemm_pk wants for a shape: about one wave per SIMD (tiles x splits ~ 4 x CUs), every slice >= 4 chunks of 8. */
 int w2e_gemm_pk_splits(int m, int n, int k);
+/* OPT-IN fp16 operands for the same GEMM (CLIP(...).set_precision("f16"); never the default): the arithmetic of the tower the reference
+ * actually runs on a GPU -- criteria/clip_loss.py:10 `clip.load("ViT-B/32", device="cuda")` is OpenAI's fp16 model -- for the four Linear
+ * layers of a block.  w2e_pack_kq_h packs X (or X^T) as fp16, PH[(s*2+h)*rows_padded + r] = the 8 halves X[r][16s+4h+c], X[r][16s+8+4h+c],
+ * c = 0..3 -- the k a lane-half of one v_mfma_f32_32x32x16_f16 step holds when its A operand comes from two consecutive chunks of the
+ * fp32 packing above.  w2e_gemm_pk_h: A stays the fp32 K-quad-major operand its producers write and is rounded to fp16 (nearest even) in
+ * registers; B is the fp16 pack; fp32 accumulation; the same slabs.  K %% 16 == 0. */
+int w2e_pack_kq_h(const float* x, void* packed_half, int rows, int rows_padded, int k, int ldx, int transposed, void* stream);
+int w2e_gemm_pk_h(const float* a_packed, const void* b_packed_half, float* c, int m, int n, int k, int m_padded, int n_padded, int ldc,
+                  int splits, void* stream);
+int w2e_gemm_pk_h_splits(int m, int n, int k);
 
 /* ---- the scalar tail of a mapper step (csrc/losstail.hip): ~37 [B,T]- / [B,18,512]-sized stock launches as four -------------------
  * criteria/clip_loss.py:16 + the tail of OpenAI clip.model.CLIP.forward: out[b,t] = exp(*logit_scale) * <f_b, t_t> / (|f_b| |t_t|)

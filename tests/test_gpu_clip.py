@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import seeded
-from helpers import assert_close, golden
+from helpers import assert_close, golden, rel_err
 from make_golden import CLIP_TINY
 from oracle import clip_model as OC
 
@@ -306,3 +306,82 @@ def test_gemm_pk_and_its_packing_vs_float64(m, n, k):
         assert_close(c.double().sum(0), ref, 5e-6, f"gemm_pk, {sp} slabs")  # (fp32 sums over up to 3072 terms)
         tried += 1
     assert tried >= 2
+
+
+@pytest.mark.parametrize("m,n,k", [(200, 2304, 768), (200, 768, 3072), (400, 3072, 768), (50, 768, 768), (77, 200, 112)])
+def test_gemm_pk_h_is_the_fp16_rounding_of_its_operands(m, n, k):
+    """The opt-in fp16-operand GEMM (w2e_pack_kq_h + w2e_gemm_pk_h): exactly A and W rounded to fp16 (nearest even), products and sums in
+    fp32 -- compared with a float64 product of the ROUNDED operands at fp32 accumulation accuracy, plain and transposed weight packs,
+    every admissible split count; and against the unrounded product to show what the rounding costs (printed by -s)."""
+    from where2edit_amd import _lib
+    from where2edit_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(3 * m + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV)
+    mpad, npad = -(-m // 32) * 32, -(-n // 64) * 64
+    ap = torch.empty((k // 4, mpad, 4), device=DEV)
+    call("w2e_pack_kq", ptr(a), ptr(ap), m, mpad, k, k, 0, stream_ptr())
+    wh = torch.empty((k // 8, npad, 8), device=DEV, dtype=torch.float16)
+    call("w2e_pack_kq_h", ptr(w), wh.data_ptr(), n, npad, k, k, 0, stream_ptr())
+    wh2 = torch.empty_like(wh)
+    call("w2e_pack_kq_h", ptr(w.t().contiguous()), wh2.data_ptr(), n, npad, k, n, 1, stream_ptr())
+    assert torch.equal(wh, wh2), "plain and transposed fp16 packs differ"
+    # the pack holds fp16(W) at k = 16 s + 8 (c >> 2) + 4 h + (c & 3) for entry (s, h), component c
+    wr = wh[:, :n].float().reshape(k // 16, 2, n, 2, 4).permute(2, 0, 3, 1, 4).reshape(n, k)
+    assert torch.equal(wr, w.half().float()), "fp16 pack is not round-to-nearest of W in the documented k order"
+    ref_h = a.half().double() @ w.half().double().t()
+    ref = a.double() @ w.double().t()
+    steps = k // 16
+    pick = _lib.load().w2e_gemm_pk_h_splits(m, n, k)
+    tried = 0
+    for sp in sorted({1, 2, 3, pick}):
+        per = -(-(-(-steps // sp)) // 4) * 4
+        if sp > steps or (sp - 1) * per >= steps:
+            continue
+        c = torch.full((sp, m, n), float("nan"), device=DEV)
+        call("w2e_gemm_pk_h", ptr(ap), wh.data_ptr(), ptr(c), m, n, k, mpad, npad, n, sp, stream_ptr())
+        assert_close(c.double().sum(0), ref_h, 5e-6, f"gemm_pk_h, {sp} slabs, against the rounded operands")
+        tried += 1
+    assert tried >= 2
+    print(f"fp16 operands, K = {k}: |C_h - C| / |C| = {rel_err(c.double().sum(0), ref):.2e}")
+    with pytest.raises(RuntimeError, match="K %% 16|K % 16"):
+        call("w2e_gemm_pk_h", ptr(ap), wh.data_ptr(), ptr(c), m, n, 104, mpad, npad, n, 1, stream_ptr())
+
+
+def test_vit_b32_tower_with_fp16_operands_against_the_fp32_tower_and_the_oracle():
+    """CLIP.set_precision("f16") (opt-in; what the reference's GPU tower computes: fp16 Linear operands, fp32 accumulation here): the
+    image features and the image gradient of ViT-B/32 against the default fp32 tower and against the fp32 CPU oracle, with the measured
+    errors printed; the four block GEMMs run on w2e_gemm_pk_h, everything else is the fp32 path; switching back restores the fp32
+    results bit for bit in deterministic terms (same kernels, same packs)."""
+    cfg = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch=32, context_length=8,
+               vocab_size=64, text_width=64, text_layers=1)
+    m, sd = _model(cfg)
+    img = seeded.tensor("clip.f16.img", (4, 3, 224, 224), 0.5)
+    r = seeded.tensor("clip.f16.r", (4, 512))
+
+    def run():
+        ig = img.to(DEV).requires_grad_(True)
+        f = m.encode_image(ig)
+        (g,) = torch.autograd.grad((f * r.to(DEV)).sum(), ig)
+        return f.detach(), g
+
+    f32, g32 = run()
+    m.set_precision("f16")
+    try:
+        f16, g16 = run()
+    finally:
+        m.set_precision("f32")
+    f32b, g32b = run()
+    assert_close(f32b, f32, 1e-6, "fp32 tower after switching back"), assert_close(g32b, g32, 1e-5, "fp32 gradient after switching back")
+    assert not torch.equal(f16, f32), "the fp16 switch changed nothing"
+    io = img.clone().requires_grad_(True)
+    fo = OC.encode_image(sd, io)
+    (go,) = torch.autograd.grad((fo * r).sum(), io)
+    e_f, e_g = rel_err(f16, f32), rel_err(g16, g32)
+    cos = torch.nn.functional.cosine_similarity(g16.flatten().double(), g32.flatten().double(), dim=0).item()
+    print(f"fp16-operand tower vs fp32 tower: features {e_f:.2e}, image gradient {e_g:.2e} (cosine {cos:.6f}); "
+          f"vs the fp32 oracle: features {rel_err(f16, fo):.2e}, gradient {rel_err(g16, go):.2e}")
+    # fp16 has an 11-bit significand (2^-11 = 4.9e-4 per operand); measured on MI355X (profiles/r05_clip_f16.txt): features 4.7e-4,
+    # image gradient 9.3e-4, cosine 1.000000 -- held to twice / three times that
+    assert e_f <= 1e-3 and e_g <= 3e-3 and cos >= 0.99999, (e_f, e_g, cos)
+    assert_close(f16, fo, 1e-3, "fp16-operand features vs the fp32 oracle")

@@ -61,3 +61,21 @@ for name, n, k in SHAPES:
     gf = 2.0 * M * n * k / 1e9
     print(f"{name:18s} M={M} N={n} K={k} ({gf:.2f} GF)  pick x{pick} | pack A {tp:4.1f} us | gemm_pk " +
           "  ".join(f"x{sp}:{t:5.1f}" for sp, t in res), flush=True)
+    # the opt-in fp16-operand form (w2e_gemm_pk_h): fp16 weight pack, A rounded in registers
+    wh = torch.empty((k // 8, np_, 8), device="cuda", dtype=torch.float16)
+    call("w2e_pack_kq_h", ptr(w), wh.data_ptr(), n, np_, k, k, 0, stream_ptr())
+    ref_h = a.half().double() @ w.half().double().t()
+    res_h = []
+    for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+        steps = k // 16
+        per = -(-(-(-steps // sp)) // 4) * 4
+        if sp > steps // 4 or (sp - 1) * per >= steps:
+            continue
+        c = torch.empty((sp, M, n), device="cuda")
+        run = lambda: call("w2e_gemm_pk_h", ptr(ap), wh.data_ptr(), ptr(c), M, n, k, mp, np_, n, sp, stream_ptr())
+        run()
+        err = ((c.double().sum(0) - ref_h).abs().max() / ref_h.abs().max()).item()
+        assert err < 1e-5, (name, sp, err)
+        res_h.append((sp, timeit(run)))
+    pick_h = _lib.load().w2e_gemm_pk_h_splits(M, n, k)
+    print(f"{'':18s} fp16 operands: pick x{pick_h} | gemm_pk_h " + "  ".join(f"x{sp}:{t:5.1f}" for sp, t in res_h), flush=True)

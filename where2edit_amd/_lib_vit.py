@@ -19,6 +19,9 @@ PROTOS = {
     "w2e_pack_kq": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "w2e_gemm_pk": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "w2e_gemm_pk_splits": (_I, [_I, _I, _I]),
+    "w2e_pack_kq_h": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "w2e_gemm_pk_h": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "w2e_gemm_pk_h_splits": (_I, [_I, _I, _I]),
     "w2e_clip_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_clip_logits_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "w2e_step_loss_fwd": (_I, [_P, _I, _P, _P, _L, _F, _F, _P, _P]),

@@ -104,6 +104,16 @@ class VisionTransformer(nn.Module):
         from . import vit_hip
         return vit_hip.vision_forward(self, x)
 
+    def set_precision(self, precision):
+        """"f32" (default: every GEMM on the exact fp32 MFMA) or the OPT-IN "f16": the four Linear layers of every block take fp16
+        operands with fp32 accumulation (w2e_gemm_pk_h) -- the arithmetic of the model the reference loads on a GPU
+        (criteria/clip_loss.py:10: `clip.load(..., device="cuda")` is OpenAI's fp16 tower); LayerNorm, attention, GELU and the
+        residual stream stay fp32.  Widths the packed-operand kernels are not instantiated for ignore it."""
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16'")
+        self._w2e_precision = precision
+        return self
+
 
 class CLIP(nn.Module):
     """ViT variants of OpenAI CLIP.  Default arguments = "ViT-B/32"."""
@@ -126,6 +136,11 @@ class CLIP(nn.Module):
     @property
     def dtype(self):
         return self.visual.conv1.weight.dtype
+
+    def set_precision(self, precision):
+        """The image tower's GEMM operand precision: see VisionTransformer.set_precision (parameters and I/O stay fp32)."""
+        self.visual.set_precision(precision)
+        return self
 
     def encode_image(self, image):
         return self.visual(image.to(self.dtype))

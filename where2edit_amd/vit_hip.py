@@ -275,8 +275,9 @@ class _WeightsPk:
     """K-quad-major packed copies of the frozen Linear weights (w2e_pack_kq): `fwd(w)` for y = x W^T (contraction over W's columns),
     `bwd(w)` for gx = gy W (contraction over W's rows: the packed form of W^T).  Built once per weight version: +2 x 340 MB for ViT-B/32."""
 
-    def __init__(self):
+    def __init__(self, half=False):
         self.cache = {}
+        self.half = bool(half)  # opt-in: fp16 packs for w2e_gemm_pk_h (VisionTransformer.set_precision("f16"))
 
     def _get(self, w, transposed):
         key = (w.data_ptr(), w._version)
@@ -285,9 +286,15 @@ class _WeightsPk:
             wd = w.detach()
             n, k = (wd.shape[1], wd.shape[0]) if transposed else (wd.shape[0], wd.shape[1])  # output columns, contraction length
             npad = _pad(n, 64)
-            p = torch.empty((k // 4, npad, 4), device=w.device, dtype=torch.float32)
-            call("w2e_pack_kq", ptr(_c(wd)), ptr(p), n, npad, k, wd.stride(0), int(transposed), stream_ptr())
-            hit = (key, (p, n, k, npad))
+            if self.half:
+                if k % 16:
+                    raise ValueError(f"fp16 tower GEMM: contraction length {k} is not a multiple of 16")
+                p = torch.empty((k // 8, npad, 8), device=w.device, dtype=torch.float16)
+                call("w2e_pack_kq_h", ptr(_c(wd)), p.data_ptr(), n, npad, k, wd.stride(0), int(transposed), stream_ptr())
+            else:
+                p = torch.empty((k // 4, npad, 4), device=w.device, dtype=torch.float32)
+                call("w2e_pack_kq", ptr(_c(wd)), ptr(p), n, npad, k, wd.stride(0), int(transposed), stream_ptr())
+            hit = (key, (p, n, k, npad, self.half))
             self.cache[(id(w), transposed)] = hit
         return hit[1]
 
@@ -303,15 +310,18 @@ _PK_SPLITS = {}
 
 def _gemm_pk(a_packed, m, mpad, wpk):
     """[S, m, n] slabs = A x W^T on w2e_gemm_pk: both operands K-quad-major, one independent wave per (32 rows, 64 columns, K slice)."""
-    wp, n, k, npad = wpk
-    key = (m, n, k, a_packed.device.index)  # (the plan depends on the CU count of the device the launch goes to)
+    wp, n, k, npad, half = wpk
+    key = (m, n, k, a_packed.device.index, half)  # (the plan depends on the CU count of the device the launch goes to)
     if key not in _PK_SPLITS:
         from . import _lib
-        _PK_SPLITS[key] = _lib.load().w2e_gemm_pk_splits(m, n, k)
+        _PK_SPLITS[key] = (_lib.load().w2e_gemm_pk_h_splits if half else _lib.load().w2e_gemm_pk_splits)(m, n, k)
     sp = _PK_SPLITS[key]
     c = torch.empty((sp, m, n), device=a_packed.device, dtype=torch.float32)
     prof = profiling.span("vit_gemm", 2.0 * m * n * k)
-    call("w2e_gemm_pk", ptr(a_packed), ptr(wp), ptr(c), m, n, k, mpad, npad, n, sp, stream_ptr())
+    if half:  # (A stays the fp32 packed operand its producer wrote: rounded to fp16 in the kernel's registers)
+        call("w2e_gemm_pk_h", ptr(a_packed), wp.data_ptr(), ptr(c), m, n, k, mpad, npad, n, sp, stream_ptr())
+    else:
+        call("w2e_gemm_pk", ptr(a_packed), ptr(wp), ptr(c), m, n, k, mpad, npad, n, sp, stream_ptr())
     if prof is not None:
         prof.end()
     return c
@@ -407,8 +417,9 @@ def vision_forward(vit, image):
     x = torch.cat([vit.class_embedding.view(1, 1, width).expand(b, 1, width), x], dim=1) + vit.positional_embedding
     x = layer_norm(x, vit.ln_pre)
     if _v2_ok(vit, width):
-        if not hasattr(vit, "_wpk"):
-            vit._wpk = _WeightsPk()
+        half = getattr(vit, "_w2e_precision", "f32") == "f16"
+        if not hasattr(vit, "_wpk") or vit._wpk.half != half:
+            vit._wpk = _WeightsPk(half)
         x = _TransformerV3.apply(x, vit.heads, vit._wpk, list(vit.transformer.resblocks))
     else:  # widths the M = 50*batch kernels are not instantiated for (the tests' tiny tower): first-generation kernels
         arena = None if os.environ.get("W2E_TUNE_NO_ARENA") else _ZeroArena(len(vit.transformer.resblocks), x.device)
