@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define W2E_VERSION 4
+/* 5: additive over 4 -- w2e_pack_kq_h / w2e_gemm_pk_h / w2e_gemm_pk_h_splits (w2e_vit.h), the options tune_xcd / tune_mw; no existing
+ * signature changed */
+#define W2E_VERSION 5
 
 int w2e_version(void);
 const char* w2e_last_error(void);
