@@ -363,12 +363,12 @@ def capture_graph(body, what, device, warmup=3, leaves=()):
     finally:
         for h in hooks:
             h.remove()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
     if seen - {side.cuda_stream}:
         raise RuntimeError(f"{what}: an autograd graph from an earlier eager step still references the parameters (their gradient "
                            "accumulation ran on another stream than the warm-up's) -- capturing now would pull that stream into the "
                            "graph and crash in hipStreamEndCapture.  Drop the old loss / output tensors (del them) before capturing.")
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
     memset_guard(body, what)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
