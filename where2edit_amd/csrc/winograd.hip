@@ -84,7 +84,8 @@ typedef float wf_f32x2 __attribute__((ext_vector_type(2)));
 // costs MFMA cycles PLUS transform cycles (2304 + ~900 of the 4200 measured), never their maximum, and the only way to make the
 // transform cheaper per MFMA is to share it between more output channels.  With 8 matrix waves the accumulators take 144 of a wave's
 // 168 registers: the A operands come through a ring of three positions instead of a tick ahead, and the output items (which need ~60
-// registers beside live accumulators) are all run by the transform waves, two per thread and round, in four rounds of 16 channels.
+// registers beside live accumulators) are run, in four rounds of 16 channels, by the transform waves and the matrix waves of channel half
+// 0 -- whose accumulators are half dead in round 0 and dead from round 1 on; half 1's stay live until round 3 (`matrix_role`).
 template <int ACT, bool DOT, int TXN, int MW>
 __global__ __launch_bounds__(64 * (MW + 4), 1) void wino4_fused3_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                                               const float* __restrict__ uf, const float* __restrict__ out_scale,
